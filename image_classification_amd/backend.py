@@ -1,0 +1,73 @@
+"""The compute backend the host-side mirrors call.
+
+`HipBackend` is the only backend this package ships: every method is one C-ABI call into
+libic_hip.so (see ops.py).  The host logic (batching, sharding, the Lloyd loop, the collectives)
+takes the backend as an argument so that the multi-process tests can drive that logic on CPU-only
+machines with a checker backend of their own; nothing in the package ever substitutes one.
+"""
+import torch
+
+from . import device as _device
+from . import ops
+
+
+class HipBackend(object):
+    name = "hip-gfx950"
+
+    def __init__(self, device=None):
+        self.device = device or _device.default_device()
+
+    # -- data movement -------------------------------------------------------------------------
+    def f32(self, a):
+        return ops.as_device_f32(a, self.device)
+
+    def i32(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.as_tensor(a, dtype=torch.int32).to(self.device)
+
+    def i64(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int64).contiguous()
+        return torch.as_tensor(a, dtype=torch.int64).to(self.device)
+
+    def codebook(self, c):
+        return _device.resident(c, self.device)
+
+    # -- operators -----------------------------------------------------------------------------
+    def assign_top1(self, x, cb, want_dist=True):
+        return ops.assign_top1(x, cb.c, cb.sqnorm, want_dist)
+
+    def assign_top2(self, x, cb, ratio=0.8):
+        return ops.assign_top2(x, cb.c, ratio, cb.sqnorm)
+
+    def assign_top2_rec(self, x, cb):
+        return ops.assign_top2_rec(x, cb.c, cb.sqnorm)
+
+    def top2_merge(self, gathered, shard_base, ratio=0.8):
+        return ops.top2_merge(gathered, shard_base, ratio)
+
+    def hist(self, codes, offsets, k, norm="l1", power=0.5):
+        return ops.hist(codes, offsets, k, norm, power)
+
+    def centroid_partials(self, x, codes, k):
+        return ops.centroid_partials(x, codes, k)
+
+    def centroid_finalize(self, sums, counts, prev_c):
+        return ops.centroid_finalize(sums, counts, prev_c)
+
+    def make_codebook(self, c_dev):
+        """Wrap a device tensor produced by centroid_finalize as a codebook."""
+        return _device.ResidentCodebook(c_dev, self.device)
+
+
+_default = {}
+
+
+def default_backend():
+    dev = _device.default_device()
+    key = str(dev)
+    b = _default.get(key)
+    if b is None:
+        b = _default[key] = HipBackend(dev)
+    return b

@@ -1,0 +1,106 @@
+"""k-means on the device: the assign step and the Lloyd loop.
+
+The reference's own file of this name (model/clustering.py:19-177) is hierarchical clustering and
+contains no k-means; the nearest-codeword assignment and Lloyd iterations this module provides are
+what the reference reaches through scipy: `vq` at model/features.py:1166 and
+`kmeans2(features, k, iter=iterations, minit='points')` at vision/facerec/face_indexing.py:156-161.
+Semantics follow scipy's kmeans2 loop: per iteration assign (lowest index on ties), then the mean
+of each cluster's members in float64, an empty cluster keeps its previous centroid, and the labels
+returned are those of the last assignment, i.e. from before the last update.
+"""
+import warnings
+
+import numpy as np
+
+from .backend import default_backend
+
+
+def kmeans_assign(x, codebook, backend=None, return_dist=False):
+    """Nearest-codeword index (int32) of every row of x; optionally the Euclidean distance."""
+    b = backend or default_backend()
+    xd = b.f32(x)
+    cb = b.codebook(codebook)
+    idx, dist = b.assign_top1(xd, cb, want_dist=return_dist)
+    idx = idx.cpu().numpy()
+    if return_dist:
+        return idx, dist.cpu().numpy()
+    return idx
+
+
+def lloyd(xd, c0, iters, backend, allreduce=None, on_empty=None):
+    """Run `iters` Lloyd iterations on device-resident rows.
+
+    xd: float32 device tensor [n, d] (this process's rows); c0: float32 device tensor [k, d].
+    allreduce(sums, counts): in-place sum over processes, or None for a single process.
+    on_empty(): called once per iteration that left some cluster without members.
+    Returns (codebook device tensor, labels int32 device tensor, empties per iteration).
+    """
+    cb = backend.make_codebook(c0)
+    k = c0.shape[0]
+    labels = None
+    empties = []
+    for _ in range(int(iters)):
+        labels, _dist = backend.assign_top1(xd, cb, want_dist=False)
+        sums, counts = backend.centroid_partials(xd, labels, k)
+        if allreduce is not None:
+            allreduce(sums, counts)
+        new_c, has = backend.centroid_finalize(sums, counts, cb.c)
+        n_empty = int(k - int(has.sum().item()))
+        empties.append(n_empty)
+        if n_empty and on_empty is not None:
+            on_empty()
+        cb = backend.make_codebook(new_c)
+    return cb.c, labels, empties
+
+
+def _warn_empty():
+    warnings.warn("One of the clusters is empty. Re-run kmeans with a different initialization.",
+                  stacklevel=3)
+
+
+def kmeans_fit(x, k, iters=10, minit="points", missing="warn", rng=None, backend=None):
+    """scipy.cluster.vq.kmeans2 semantics on the device.  Returns (codebook, labels) as numpy."""
+    if int(iters) < 1:
+        raise ValueError("Invalid iter (%s), must be a positive integer." % iters)
+    if missing not in ("warn", "raise"):
+        raise ValueError("Unknown missing method %r" % (missing,))
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    if x.ndim != 2:
+        raise ValueError("Input of rank > 2 is not supported.")
+    if x.size < 1:
+        raise ValueError("Empty input is not supported.")
+    karr = np.asarray(k)
+    if minit == "matrix" or karr.size > 1:
+        init = np.array(karr, copy=True)
+        if init.ndim == 1:
+            init = init[:, None]
+        if init.ndim != x.ndim:
+            raise ValueError("k array doesn't match data rank")
+        if init.shape[1] != x.shape[1]:
+            raise ValueError("k array doesn't match data dimension")
+    else:
+        nc = int(karr)
+        if nc < 1:
+            raise ValueError("Cannot ask kmeans2 for %d clusters (k was %s)" % (nc, k))
+        if minit != "points":
+            raise ValueError("minit %r is not supported on the device; use 'points' or 'matrix'"
+                             % (minit,))
+        if nc > x.shape[0]:
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        if rng is None or isinstance(rng, (int, np.integer)):
+            rng = np.random.default_rng(rng)
+        init = x[rng.choice(x.shape[0], size=nc, replace=False)]
+
+    def on_empty():
+        if missing == "raise":
+            raise RuntimeError("One of the clusters is empty. "
+                               "Re-run kmeans with a different initialization.")
+        _warn_empty()
+
+    b = backend or default_backend()
+    xd = b.f32(x)
+    c, labels, _ = lloyd(xd, b.f32(init), iters, b, on_empty=on_empty)
+    out_dtype = x.dtype if x.dtype.kind == "f" else np.float64
+    return c.cpu().numpy().astype(out_dtype), labels.cpu().numpy()

@@ -1,0 +1,334 @@
+// C ABI of libic_hip.so (declared in include/ic_hip.h): handle, workspace, argument checks and the
+// launch sequences.  No kernel lives here.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "ic_internal.h"
+
+namespace {
+
+thread_local std::string t_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  t_err = buf;
+  return code;
+}
+
+int fail_hip(hipError_t e, const char* what) {
+  return fail((int)e, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+}
+
+constexpr uint64_t kMagic = 0x1c41ffa5d15c0de5ULL;
+
+struct Ctx {
+  uint64_t magic = kMagic;
+  int device = 0;
+  int num_cus = 256;
+  std::mutex mu;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  hipEvent_t done = nullptr;      // recorded after each call's last launch
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
+};
+
+Ctx* as_ctx(void* h) {
+  Ctx* c = static_cast<Ctx*>(h);
+  if (!c || c->magic != kMagic) return nullptr;
+  return c;
+}
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// RAII: make the handle's device current for the call, restore the caller's afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err != hipSuccess) { ok = false; return; }
+    if (prev != dev) {
+      err = hipSetDevice(dev);
+      if (err != hipSuccess) ok = false;
+    } else {
+      prev = -1;
+    }
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// Grow-only workspace.  Growing waits for everything in flight on the device before the old
+// block is released.
+int ensure_ws(Ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return IC_OK;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail_hip(e, "hipDeviceSynchronize before workspace growth");
+  if (c->ws) {
+    (void)hipFree(c->ws);
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  const size_t want = align_up(bytes + bytes / 4, 1 << 20);
+  e = hipMalloc(reinterpret_cast<void**>(&c->ws), want);
+  if (e != hipSuccess) {
+    c->ws = nullptr;
+    return fail(IC_ENOMEM, "workspace allocation of %zu bytes failed: %s", want,
+                hipGetErrorString(e));
+  }
+  c->ws_bytes = want;
+  return IC_OK;
+}
+
+// The workspace is shared by consecutive calls: a call on another stream than the previous one
+// first waits (on the device) for the previous call's work.
+int order_after_previous(Ctx* c, hipStream_t s) {
+  if (c->have_last && c->last_stream != s) {
+    hipError_t e = hipStreamWaitEvent(s, c->done, 0);
+    if (e != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
+  }
+  return IC_OK;
+}
+
+int finish_call(Ctx* c, hipStream_t s) {
+  hipError_t e = hipEventRecord(c->done, s);
+  if (e != hipSuccess) return fail_hip(e, "hipEventRecord");
+  c->last_stream = s;
+  c->have_last = true;
+  return IC_OK;
+}
+
+#define IC_HIP(call, what)                            \
+  do {                                                \
+    hipError_t e__ = (call);                          \
+    if (e__ != hipSuccess) return fail_hip(e__, what); \
+  } while (0)
+
+// Shared body of the three search entry points.
+int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                uint8_t* mask, ic_top2_rec* rec, void* stream, const char* who) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "%s: invalid handle", who);
+  if (n < 0 || k < 1 || k > 0x7fffffffLL) return fail(IC_EINVAL, "%s: need n >= 0 and 1 <= k < 2^31 (n=%lld k=%lld)", who, (long long)n, (long long)k);
+  if (d < 1 || d > ic::kD) return fail(IC_EINVAL, "%s: descriptor dimension %d not in [1,%d]", who, d, ic::kD);
+  if (n == 0) return IC_OK;
+  if (!x || !c) return fail(IC_EINVAL, "%s: x and c must not be NULL", who);
+  if (!i1 && !rec) return fail(IC_EINVAL, "%s: no output buffer given", who);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+
+  const int64_t kpad = (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
+  const int nsplit = ic::assign_choose_nsplit(n, k, ctx->num_cus);
+  const bool pad = d != ic::kD;
+  size_t off = 0;
+  const size_t o_cn = off;   off += align_up((size_t)kpad * 4);
+  const size_t o_part = off; off += align_up((size_t)nsplit * (size_t)n * sizeof(ic_top2_rec));
+  const size_t o_xp = off;   if (pad) off += align_up((size_t)n * ic::kD * 4);
+  const size_t o_cp = off;   if (pad) off += align_up((size_t)k * ic::kD * 4);
+  int rc = ensure_ws(ctx, off);
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+
+  float* cn = reinterpret_cast<float*>(ctx->ws + o_cn);
+  ic_top2_rec* part = reinterpret_cast<ic_top2_rec*>(ctx->ws + o_part);
+  const float* xs = x;
+  const float* cs = c;
+  if (pad) {
+    float* xp = reinterpret_cast<float*>(ctx->ws + o_xp);
+    float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
+    IC_HIP(ic::launch_pad_rows(x, n, d, xp, s), "pad descriptors");
+    IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
+    xs = xp;
+    cs = cp;
+  }
+  IC_HIP(ic::launch_codebook_norms(cs, k, kpad, c_sqnorm, cn, s), "codebook norms");
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, nsplit, part, s), "distance/top-2 kernel");
+  IC_HIP(ic::launch_rescore(xs, n, cs, part, nsplit, i1, d1, i2, d2, ratio, mask, rec, s),
+         "rescore kernel");
+  return finish_call(ctx, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ic_version(void) { return 100; }
+
+const char* ic_last_error(void* /*handle*/) { return t_err.c_str(); }
+
+int ic_create(int device, void** handle) {
+  if (!handle) return fail(IC_EINVAL, "ic_create: handle pointer is NULL");
+  *handle = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount");
+  if (device < 0 || device >= count)
+    return fail(IC_EINVAL, "ic_create: device %d not in [0,%d)", device, count);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(IC_EINVAL, "ic_create: device %d is %s; this library holds gfx950 code only",
+                device, prop.gcnArchName);
+  Ctx* c = new (std::nothrow) Ctx();
+  if (!c) return fail(IC_ENOMEM, "ic_create: out of host memory");
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  DeviceGuard guard(device);
+  if (!guard.ok) { delete c; return fail_hip(guard.err, "hipSetDevice"); }
+  e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+  if (e != hipSuccess) { delete c; return fail_hip(e, "hipEventCreate"); }
+  *handle = c;
+  return IC_OK;
+}
+
+int ic_destroy(void* handle) {
+  Ctx* c = as_ctx(handle);
+  if (!c) return fail(IC_EHANDLE, "ic_destroy: invalid handle");
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceGuard guard(c->device);
+    if (guard.ok) {
+      (void)hipDeviceSynchronize();
+      if (c->ws) (void)hipFree(c->ws);
+      if (c->done) (void)hipEventDestroy(c->done);
+    }
+    c->ws = nullptr;
+    c->magic = 0;
+  }
+  delete c;
+  return IC_OK;
+}
+
+int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_row_sqnorm: invalid handle");
+  if (n < 0 || d < 1) return fail(IC_EINVAL, "ic_row_sqnorm: bad shape n=%lld d=%d", (long long)n, d);
+  if (n == 0) return IC_OK;
+  if (!x || !out) return fail(IC_EINVAL, "ic_row_sqnorm: NULL pointer");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  IC_HIP(ic::launch_row_sqnorm(x, n, d, out, static_cast<hipStream_t>(stream)), "row norms");
+  return IC_OK;
+}
+
+int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                   const float* c_sqnorm, int32_t* idx, float* dist, void* stream) {
+  if (!idx) return fail(IC_EINVAL, "ic_assign_top1: idx is NULL");
+  return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
+                     nullptr, stream, "ic_assign_top1");
+}
+
+int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                   const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2,
+                   float ratio, uint8_t* mask, void* stream) {
+  if (!i1) return fail(IC_EINVAL, "ic_assign_top2: i1 is NULL");
+  return assign_impl(handle, x, n, c, k, d, c_sqnorm, i1, d1, i2, d2, ratio, mask, nullptr, stream,
+                     "ic_assign_top2");
+}
+
+int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                       const float* c_sqnorm, ic_top2_rec* rec, void* stream) {
+  if (!rec) return fail(IC_EINVAL, "ic_assign_top2_rec: rec is NULL");
+  return assign_impl(handle, x, n, c, k, d, c_sqnorm, nullptr, nullptr, nullptr, nullptr, 0.f,
+                     nullptr, rec, stream, "ic_assign_top2_rec");
+}
+
+int ic_top2_merge(void* handle, const ic_top2_rec* gathered, int n_shards, int64_t n,
+                  const int64_t* shard_base, int64_t* i1, float* d1, int64_t* i2, float* d2,
+                  float ratio, uint8_t* mask, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_top2_merge: invalid handle");
+  if (n < 0 || n_shards < 1 || n_shards > ic::kMaxShards)
+    return fail(IC_EINVAL, "ic_top2_merge: need n >= 0 and 1 <= n_shards <= %d", ic::kMaxShards);
+  if (n == 0) return IC_OK;
+  if (!gathered || !shard_base || !i1) return fail(IC_EINVAL, "ic_top2_merge: NULL pointer");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  IC_HIP(ic::launch_top2_merge(gathered, n_shards, n, shard_base, i1, d1, i2, d2, ratio, mask,
+                               static_cast<hipStream_t>(stream)),
+         "top-2 merge kernel");
+  return IC_OK;
+}
+
+int ic_hist(void* handle, const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
+            int norm_mode, double power, double* out, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_hist: invalid handle");
+  if (n_img < 0 || k < 1) return fail(IC_EINVAL, "ic_hist: bad shape n_img=%lld k=%lld", (long long)n_img, (long long)k);
+  if (norm_mode < IC_NORM_NONE || norm_mode > IC_NORM_POWER_L2)
+    return fail(IC_EINVAL, "ic_hist: unknown norm_mode %d", norm_mode);
+  if (n_img == 0) return IC_OK;
+  if (!offsets || !out) return fail(IC_EINVAL, "ic_hist: NULL pointer");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  IC_HIP(ic::launch_hist(codes, offsets, n_img, k, norm_mode, power, out,
+                         static_cast<hipStream_t>(stream)),
+         "histogram kernel");
+  return IC_OK;
+}
+
+int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int64_t n, int64_t k,
+                         int d, double* sums, int64_t* counts, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_centroid_partials: invalid handle");
+  if (n < 0 || k < 1 || d < 1 || d > ic::kD)
+    return fail(IC_EINVAL, "ic_centroid_partials: bad shape n=%lld k=%lld d=%d", (long long)n, (long long)k, d);
+  if (!sums || !counts || (n > 0 && (!x || !codes)))
+    return fail(IC_EINVAL, "ic_centroid_partials: NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  int n_rr = 1;
+  ic::centroid_plan(n, k, ctx->num_cus, &n_rr);
+  size_t off = 0;
+  const size_t o_ps = off; if (n_rr > 1) off += align_up((size_t)n_rr * (size_t)k * d * 8);
+  const size_t o_pc = off; if (n_rr > 1) off += align_up((size_t)n_rr * (size_t)k * 8);
+  int rc = ensure_ws(ctx, off);
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+  IC_HIP(ic::launch_centroid_partials(x, codes, n, k, d, n_rr,
+                                      reinterpret_cast<double*>(ctx->ws + o_ps),
+                                      reinterpret_cast<int64_t*>(ctx->ws + o_pc), sums, counts, s),
+         "centroid sums kernel");
+  return finish_call(ctx, s);
+}
+
+int ic_centroid_finalize(void* handle, const double* sums, const int64_t* counts,
+                         const float* prev_c, int64_t k, int d, float* new_c,
+                         uint8_t* has_members, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_centroid_finalize: invalid handle");
+  if (k < 1 || d < 1) return fail(IC_EINVAL, "ic_centroid_finalize: bad shape k=%lld d=%d", (long long)k, d);
+  if (!sums || !counts || !prev_c || !new_c) return fail(IC_EINVAL, "ic_centroid_finalize: NULL pointer");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  IC_HIP(ic::launch_centroid_finalize(sums, counts, prev_c, k, d, new_c, has_members,
+                                      static_cast<hipStream_t>(stream)),
+         "centroid finalize kernel");
+  return IC_OK;
+}
+
+}  // extern "C"

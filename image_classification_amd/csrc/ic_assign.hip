@@ -1,0 +1,513 @@
+// Distance search kernels for gfx950 (MI355X): fused  cn - 2 x.c  on the fp32 matrix cores with a
+// running top-2 argmin kept in registers, the exact re-scoring pass, norms and the shard merge.
+//
+// What they replace in the reference (paths relative to the reference tree):
+//   scipy.cluster.vq.vq                       model/features.py:1166, vision/facerec/face_indexing.py:141
+//   argmin(euclidean_distances(squared=True)) vision/utils/scene_functions.py:391
+//   KNeighborsClassifier.kneighbors(x, 2)     model/classifiers.py:195-197 <- model/robust_matching.py:80
+//   the ratio-test loop                       model/robust_matching.py:81-84
+//
+// Layout of the main kernel (k_top2_partial):
+//   * MFMA v_mfma_f32_32x32x2_f32 with A = codeword tile (32 codewords, from LDS) and B = 32
+//     descriptors (registers).  The 32x32 result then has one DESCRIPTOR per lane and 16 CODEWORDS
+//     in that lane's registers, so the running top-2 of a descriptor never leaves its lane.
+//   * the contraction index is permuted: MFMA step s of lane half h multiplies component
+//     d = 64*h + s.  A lane therefore reads 256 contiguous bytes of "its" row for both operands.
+//   * a wave keeps XT tiles of 32 descriptors (pre-scaled by -2) in registers for the whole sweep
+//     over the codebook; the accumulator is initialised with |c|^2, so the MFMA chain leaves
+//     |c|^2 - 2 x.c directly (|x|^2 is constant per row and cannot change the argmin).
+//   * codeword tiles are staged global -> LDS with global_load_lds (16 B per lane), two stage
+//     buffers; rows are padded to 528 bytes (through the SOURCE address: the LDS image of such a
+//     load is lane-linear) so that ds_read_b128 is bank-conflict free with immediate offsets.
+//   * grid = row tiles x K-splits; every workgroup writes one (value, index) x 2 record per row,
+//     k_rescore merges the splits.
+#include "ic_internal.h"
+
+namespace ic {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileK = 32;                          // codewords per MFMA tile
+constexpr int kRowBytes = kD * 4 + 16;              // 528: one 16-byte pad chunk per codeword row
+constexpr int kRowChunks = kRowBytes / 16;          // 33
+constexpr int kStageTileBytes = kStageK * kRowBytes;  // 33792 = 33 wave-instructions of 1 KiB
+constexpr int kStageGlds = kStageTileBytes / 1024;  // 33
+constexpr int kStageBytes = kStageTileBytes + kStageK * 4;  // + 64 squared norms
+static_assert(kStageTileBytes % 1024 == 0, "a stage must be a whole number of 1 KiB pieces");
+static_assert(kStageBytes % 16 == 0, "stage buffers must stay 16-byte aligned");
+
+// Geometry of the shipped instantiation: 8 waves (two per SIMD, so one wave's top-2 update runs
+// beside the other's MFMAs), each holding 2 x 32 descriptors.
+constexpr int kXT = 2;
+constexpr int kNW = 8;
+constexpr int kRowsPerWg = kXT * kNW * 32;  // 512
+
+int assign_rows_per_wg() { return kRowsPerWg; }
+
+int assign_choose_nsplit(int64_t n, int64_t k, int num_cus) {
+  const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
+  const int64_t stages = (k + kStageK - 1) / kStageK;
+  const double overhead = 2.0;  // x-tile load + pipeline fill, in units of one stage of work
+  int best = 1;
+  double best_cost = 1e300;
+  const int64_t max_ns = stages < 256 ? stages : 256;
+  for (int64_t ns = 1; ns <= max_ns; ++ns) {
+    const int64_t per = (stages + ns - 1) / ns;
+    if ((stages + per - 1) / per != ns) continue;  // same per-split length as a smaller ns
+    const int64_t items = row_tiles * ns;
+    const int64_t rounds = (items + num_cus - 1) / num_cus;
+    const double cost = (double)rounds * ((double)per + overhead) * (1.0 + 0.002 * (double)ns);
+    if (cost < best_cost * 0.999) {
+      best_cost = cost;
+      best = (int)ns;
+    }
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const float* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// Stage `st` = codewords [64 st, 64 st + 64) -> LDS buffer sb.  The LDS image of a
+// global_load_lds is lane-linear (wave base + 16 * lane), so the padded image (528-byte rows) is
+// produced through the SOURCE address: the lane that lands on 16-byte chunk `pos` of the buffer
+// fetches chunk pos % 33 of codeword row pos / 33 (the 33rd chunk of a row is padding and re-reads
+// chunk 0).  Rows past the codebook end re-read the last row; their norm slot holds +inf, so they
+// can never win.
+template <int NW>
+__device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
+                                            const float* __restrict__ cnp, int st, char* sb,
+                                            int wave, int lane) {
+  // wave-uniform 64-bit base + 32-bit per-lane byte offset (keeps the address math off the VALU)
+  const char* base = reinterpret_cast<const char*>(C) + (size_t)st * (kStageK * kD * 4);
+  const int last = K - 1 - st * kStageK;  // last valid row of this stage (>= 0)
+  // opaque copy: the offsets below are recomputed per call (a few VALU ops) instead of being
+  // hoisted out of the sweep loop and held in registers the MFMA operands need
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (int i = 0; i < (kStageGlds + NW - 1) / NW; ++i) {
+    const int m = wave + NW * i;
+    if (m < kStageGlds) {
+      const int pos = m * 64 + lane;
+      int r = (pos * 1986) >> 16;  // pos / 33 for pos < 2112
+      int c = pos - r * kRowChunks;
+      c = c == kRowChunks - 1 ? 0 : c;
+      r = r < last ? r : last;
+      const unsigned voff = (unsigned)r * 512u + (unsigned)c * 16u;
+      glds16(reinterpret_cast<const float*>(base + voff), sb + m * 1024);
+    }
+  }
+  if (wave == NW - 1) glds4(cnp + (size_t)st * kStageK + lane, sb + kStageTileBytes);
+}
+
+struct Top2 {
+  float d1, d2;
+  int i1, i2;
+};
+
+// Strict '<' and ascending visiting order keep the lowest index on ties, as scipy's _vq.vq scan
+// and numpy's argmin do.
+__device__ __forceinline__ void top2_update(float& d1r, float& d2r, int& i1r, int& i2r, float v,
+                                            int enc) {
+  // locals only: every ?: below has plain values on both arms, so it stays a v_cndmask
+  const float d1 = d1r, d2 = d2r;
+  const int i1 = i1r, i2 = i2r;
+  const bool lt1 = v < d1;
+  const bool lt2 = v < d2;
+  const int t = lt2 ? enc : i2;
+  i2r = lt1 ? i1 : t;
+  i1r = lt1 ? enc : i1;
+  d2r = __builtin_amdgcn_fmed3f(v, d1, d2);
+  d1r = lt1 ? v : d1;
+}
+
+__device__ __forceinline__ bool lex_less(float da, int ia, float db, int ib) {
+  return da < db || (da == db && ia < ib);
+}
+
+// a and b are each ordered pairs; result = the two smallest of the four by (value, index).
+// Index -1 marks "none" (value +inf).
+__device__ __forceinline__ void top2_merge_pairs(float& d1, int& i1, float& d2, int& i2, float e1,
+                                                 int j1, float e2, int j2) {
+  // treat "none" as larger than anything real with the same value
+  auto less = [](float da, int ia, float db, int ib) {
+    if (ia < 0) return false;
+    if (ib < 0) return true;
+    return lex_less(da, ia, db, ib);
+  };
+  float r1, r2;
+  int k1, k2;
+  if (less(e1, j1, d1, i1)) {
+    r1 = e1; k1 = j1;
+    if (less(e2, j2, d1, i1)) { r2 = e2; k2 = j2; } else { r2 = d1; k2 = i1; }
+  } else {
+    r1 = d1; k1 = i1;
+    if (less(e1, j1, d2, i2)) { r2 = e1; k2 = j1; } else { r2 = d2; k2 = i2; }
+  }
+  d1 = r1; i1 = k1; d2 = r2; i2 = k2;
+}
+
+template <int XT>
+__device__ __forceinline__ void compute_tile(const char* tile_base, const char* cn_base,
+                                             const float (&xr)[XT][64], f32x16 (&acc)[XT], int i,
+                                             int h) {
+  // accumulator register g*4+e of lane half h is codeword 8g + 4h + e of the tile
+  const f32x4* cnv = reinterpret_cast<const f32x4*>(cn_base + h * 16);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 c4 = cnv[g * 2];
+#pragma unroll
+    for (int xt = 0; xt < XT; ++xt) {
+      acc[xt][g * 4 + 0] = c4[0];
+      acc[xt][g * 4 + 1] = c4[1];
+      acc[xt][g * 4 + 2] = c4[2];
+      acc[xt][g * 4 + 3] = c4[3];
+    }
+  }
+  // row stride 528 B: lanes i and i+1 start one 16-byte bank slot apart, so each 16-lane group of
+  // a ds_read_b128 covers all 16 slots of the 256-byte bank row (conflict free)
+  const f32x4* arow = reinterpret_cast<const f32x4*>(tile_base + i * kRowBytes + h * 256);
+  f32x4 a = arow[0];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    f32x4 an = a;
+    if (q + 1 < 16) an = arow[q + 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int xt = 0; xt < XT; ++xt) {
+        acc[xt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], xr[xt][q * 4 + e], acc[xt], 0, 0, 0);
+      }
+    }
+    a = an;
+  }
+}
+
+template <int XT>
+__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st)[XT], int encbase) {
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      top2_update(st[xt].d1, st[xt].d2, st[xt].i1, st[xt].i2, acc[xt][r], encbase + r);
+  }
+}
+
+template <int XT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_top2_partial(
+    const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
+    const float* __restrict__ cnp, int stages_total, int stages_per_split, int row_tiles,
+    ic_top2_rec* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;  // descriptor (B column / result column) and codeword row (A row)
+  const int h = lane >> 5;  // which half of the 128 components this lane multiplies
+
+  const int rt = blockIdx.x % row_tiles;
+  const int sp = blockIdx.x / row_tiles;
+  const int st0 = sp * stages_per_split;
+  int st1 = st0 + stages_per_split;
+  st1 = st1 < stages_total ? st1 : stages_total;
+
+  issue_stage<NW>(C, K, cnp, st0, smem, wave, lane);
+  if (st0 + 1 < st1) issue_stage<NW>(C, K, cnp, st0 + 1, smem + kStageBytes, wave, lane);
+
+  // descriptors of this wave, scaled by -2 (exact), 64 components per lane
+  const int64_t row0 = (int64_t)rt * (XT * NW * 32) + (int64_t)wave * (XT * 32);
+  float xr[XT][64];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    int64_t r = row0 + xt * 32 + j;
+    r = r < N ? r : N - 1;
+    const f32x4* p = reinterpret_cast<const f32x4*>(X + r * kD + h * 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const f32x4 v = p[q];
+      xr[xt][q * 4 + 0] = -2.0f * v[0];
+      xr[xt][q * 4 + 1] = -2.0f * v[1];
+      xr[xt][q * 4 + 2] = -2.0f * v[2];
+      xr[xt][q * 4 + 3] = -2.0f * v[3];
+    }
+  }
+
+  Top2 best[XT];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    best[xt].d1 = __builtin_inff();
+    best[xt].d2 = __builtin_inff();
+    best[xt].i1 = -1;
+    best[xt].i2 = -1;
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 acc[XT];
+  for (int st = st0; st < st1; ++st) {
+    char* sb = smem + ((st - st0) & 1) * kStageBytes;
+    compute_tile<XT>(sb, sb + kStageTileBytes, xr, acc, j, h);
+    tile_epilogue<XT>(acc, best, (st * 2) * 16);
+    compute_tile<XT>(sb + kTileK * kRowBytes, sb + kStageTileBytes + kTileK * 4, xr, acc, j, h);
+    // every wave is done reading this buffer once it passes the barrier; the stage issued one
+    // iteration ago has landed in the other buffer by then
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
+    tile_epilogue<XT>(acc, best, (st * 2 + 1) * 16);
+  }
+
+  // decode (tile, register) -> codeword index, fold the two lane halves, store
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    Top2 b = best[xt];
+    auto decode = [h](int enc) {
+      if (enc < 0) return -1;
+      const int t = enc >> 4, r = enc & 15;
+      return t * kTileK + 8 * (r >> 2) + 4 * h + (r & 3);
+    };
+    b.i1 = decode(b.i1);
+    b.i2 = decode(b.i2);
+    const float od1 = __shfl_xor(b.d1, 32);
+    const float od2 = __shfl_xor(b.d2, 32);
+    const int oi1 = __shfl_xor(b.i1, 32);
+    const int oi2 = __shfl_xor(b.i2, 32);
+    top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, od1, oi1, od2, oi2);
+    const int64_t r = row0 + xt * 32 + j;
+    if (h == 0 && r < N) {
+      ic_top2_rec rec;
+      rec.d1 = b.d1; rec.i1 = b.i1; rec.d2 = b.d2; rec.i2 = b.i2;
+      part[(int64_t)sp * N + r] = rec;
+    }
+  }
+}
+
+hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
+                               const float* cn_pad, int nsplit, ic_top2_rec* part, hipStream_t s) {
+  const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
+  const int64_t stages = (k + kStageK - 1) / kStageK;
+  const int64_t per = (stages + nsplit - 1) / nsplit;
+  auto kern = k_top2_partial<kXT, kNW>;
+  const int lds = 2 * kStageBytes;
+  // per device and cheap, so it is simply repeated on every call
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  const int64_t grid = row_tiles * nsplit;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kNW * 64), lds, s, x, n, c, (int)k, cn_pad,
+                     (int)stages, (int)per, (int)row_tiles, part);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16 lanes per row: 8 components per lane, butterfly over the 16 lanes (every lane ends with the
+// same total, fixed order => deterministic).
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 8, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 1, 16);
+  return v;
+}
+
+__device__ __forceinline__ float sqdiff8(const f32x4& x0, const f32x4& x1, const float* crow) {
+  const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow);
+  const f32x4 c1 = *reinterpret_cast<const f32x4*>(crow + 4);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float t = x0[e] - c0[e];
+    s = __builtin_fmaf(t, t, s);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float t = x1[e] - c1[e];
+    s = __builtin_fmaf(t, t, s);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
+                                                 const float* __restrict__ C,
+                                                 const ic_top2_rec* __restrict__ part, int nsplit,
+                                                 int32_t* __restrict__ i1o, float* __restrict__ d1o,
+                                                 int32_t* __restrict__ i2o, float* __restrict__ d2o,
+                                                 float ratio, uint8_t* __restrict__ mask,
+                                                 ic_top2_rec* __restrict__ reco) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
+    ic_top2_rec b = part[row];
+    for (int s = 1; s < nsplit; ++s) {
+      const ic_top2_rec o = part[(int64_t)s * N + row];
+      top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
+    }
+    const float* xrow = X + row * kD + sub * 8;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + 4);
+    float s1 = __builtin_inff(), s2 = __builtin_inff();
+    if (b.i1 >= 0) s1 = group16_sum(sqdiff8(x0, x1, C + (int64_t)b.i1 * kD + sub * 8));
+    if (b.i2 >= 0) s2 = group16_sum(sqdiff8(x0, x1, C + (int64_t)b.i2 * kD + sub * 8));
+    int a1 = b.i1, a2 = b.i2;
+    if (a2 >= 0 && lex_less(s2, a2, s1, a1)) {
+      const float ts = s1; s1 = s2; s2 = ts;
+      const int ti = a1; a1 = a2; a2 = ti;
+    }
+    const float e1 = __builtin_sqrtf(s1), e2 = __builtin_sqrtf(s2);
+    if (sub == 0) {
+      if (i1o) i1o[row] = a1;
+      if (d1o) d1o[row] = e1;
+      if (i2o) i2o[row] = a2;
+      if (d2o) d2o[row] = e2;
+      if (mask) mask[row] = (e1 < e2 * ratio) ? 1 : 0;
+      if (reco) {
+        ic_top2_rec r;
+        r.d1 = e1; r.i1 = a1; r.d2 = e2; r.i2 = a2;
+        reco[row] = r;
+      }
+    }
+  }
+}
+
+hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
+                          int nsplit, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
+  int64_t grid = (n + 15) / 16;
+  if (grid > 16384) grid = 16384;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, part, nsplit, i1,
+                     d1, i2, d2, ratio, mask, rec);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pad_rows(const float* __restrict__ src, int64_t n, int d,
+                                                  float* __restrict__ dst) {
+  const int64_t total = n * kD;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / kD;
+    const int cidx = (int)(t % kD);
+    dst[t] = cidx < d ? src[r * d + cidx] : 0.f;
+  }
+}
+
+hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s) {
+  int64_t grid = (n * kD + 255) / 256;
+  if (grid > 65536) grid = 65536;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)grid), dim3(256), 0, s, src, n, d, dst);
+  return hipGetLastError();
+}
+
+// 16 lanes per row, any d; out[row] = sum of squares (fixed order).
+__global__ __launch_bounds__(256) void k_row_sqnorm(const float* __restrict__ X, int64_t n, int d,
+                                                    int64_t npad, float* __restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < npad; row += stride) {
+    float s = 0.f;
+    if (row < n) {
+      const float* xr = X + row * d;
+      for (int cidx = sub; cidx < d; cidx += 16) s = __builtin_fmaf(xr[cidx], xr[cidx], s);
+    }
+    s = group16_sum(s);
+    if (sub == 0) out[row] = row < n ? s : __builtin_inff();
+  }
+}
+
+hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s) {
+  int64_t grid = (n + 15) / 16;
+  if (grid > 16384) grid = 16384;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)grid), dim3(256), 0, s, x, n, d, n, out);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy_pad_inf(const float* __restrict__ src, int64_t k,
+                                                      int64_t kpad, float* __restrict__ dst) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < kpad; t += (int64_t)gridDim.x * 256)
+    dst[t] = t < k ? src[t] : __builtin_inff();
+}
+
+hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const float* c_sqnorm,
+                                 float* cn_pad, hipStream_t s) {
+  if (c_sqnorm) {
+    int64_t grid = (kpad + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_copy_pad_inf, dim3((unsigned)grid), dim3(256), 0, s, c_sqnorm, k, kpad,
+                       cn_pad);
+    return hipGetLastError();
+  }
+  int64_t grid = (kpad + 15) / 16;
+  if (grid > 16384) grid = 16384;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)grid), dim3(256), 0, s, c, k, kD, kpad, cn_pad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// One thread per row: fold n_shards records (already exact Euclidean distances) by
+// (distance, global index).  The shard bases travel as a kernel argument.
+struct ShardBases {
+  int64_t b[kMaxShards];
+};
+
+__global__ __launch_bounds__(256) void k_top2_merge(const ic_top2_rec* __restrict__ g, int n_shards,
+                                                    int64_t n, ShardBases base,
+                                                    int64_t* __restrict__ i1o, float* __restrict__ d1o,
+                                                    int64_t* __restrict__ i2o, float* __restrict__ d2o,
+                                                    float ratio, uint8_t* __restrict__ mask) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  float d1 = __builtin_inff(), d2 = __builtin_inff();
+  int64_t i1 = -1, i2 = -1;
+  auto less = [](float da, int64_t ia, float db, int64_t ib) {
+    if (ia < 0) return false;
+    if (ib < 0) return true;
+    return da < db || (da == db && ia < ib);
+  };
+  auto push = [&](float d, int64_t i) {
+    if (i < 0) return;
+    if (less(d, i, d1, i1)) {
+      d2 = d1; i2 = i1; d1 = d; i1 = i;
+    } else if (less(d, i, d2, i2)) {
+      d2 = d; i2 = i;
+    }
+  };
+  for (int s = 0; s < n_shards; ++s) {
+    const ic_top2_rec r = g[(int64_t)s * n + row];
+    const int64_t b = base.b[s];
+    push(r.d1, r.i1 < 0 ? -1 : r.i1 + b);
+    push(r.d2, r.i2 < 0 ? -1 : r.i2 + b);
+  }
+  if (i1o) i1o[row] = i1;
+  if (d1o) d1o[row] = d1;
+  if (i2o) i2o[row] = i2;
+  if (d2o) d2o[row] = d2;
+  if (mask) mask[row] = (d1 < d2 * ratio) ? 1 : 0;
+}
+
+hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t n,
+                             const int64_t* shard_base_host, int64_t* i1, float* d1, int64_t* i2,
+                             float* d2, float ratio, uint8_t* mask, hipStream_t s) {
+  if (n_shards < 1 || n_shards > kMaxShards) return hipErrorInvalidValue;
+  const int64_t grid = (n + 255) / 256;
+  if (grid < 1) return hipSuccess;
+  ShardBases sb;
+  for (int i = 0; i < kMaxShards; ++i) sb.b[i] = i < n_shards ? shard_base_host[i] : 0;
+  hipLaunchKernelGGL(k_top2_merge, dim3((unsigned)grid), dim3(256), 0, s, gathered, n_shards, n,
+                     sb, i1, d1, i2, d2, ratio, mask);
+  return hipGetLastError();
+}
+
+}  // namespace ic

@@ -1,0 +1,53 @@
+// Internal launcher interface between the C-ABI layer (ic_api.hip) and the kernel files.
+// Every launcher enqueues on `stream`, never allocates and never synchronises; it returns the
+// hipError_t of the launch (hipSuccess == 0).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ic_hip.h"
+
+namespace ic {
+
+constexpr int kD = 128;      // padded descriptor dimension the MFMA kernel contracts over
+constexpr int kStageK = 64;  // codewords staged in LDS per pipeline stage (2 MFMA tiles of 32)
+constexpr int kMaxShards = 64;  // shard bases of ic_top2_merge travel as a kernel argument
+
+static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
+
+// ---- ic_assign.hip ---------------------------------------------------------------------------
+// Rows per workgroup of the distance kernel (x-tile rows kept in registers by one workgroup).
+int assign_rows_per_wg();
+// K-split chosen for a problem (>=1); the partial buffer holds nsplit * n records.
+int assign_choose_nsplit(int64_t n, int64_t k, int num_cus);
+
+hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s);
+// cn_pad[j] = |c_j|^2 for j < k (or a copy of c_sqnorm), +inf for k <= j < kpad.
+hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const float* c_sqnorm,
+                                 float* cn_pad, hipStream_t s);
+hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
+// part [nsplit][n]: per K-split (cn - 2 x.c, index) best and second best.
+hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
+                               const float* cn_pad, int nsplit, ic_top2_rec* part, hipStream_t s);
+// merge the K-splits, recompute the two distances exactly as sum (x-c)^2, order, sqrt, ratio.
+hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
+                          int nsplit, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
+hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t n,
+                             const int64_t* shard_base_host, int64_t* i1, float* d1, int64_t* i2,
+                             float* d2, float ratio, uint8_t* mask, hipStream_t s);
+
+// ---- ic_reduce.hip ---------------------------------------------------------------------------
+hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
+                       int norm_mode, double power, double* out, hipStream_t s);
+
+// Decomposition of the centroid-sum kernel: clusters per workgroup and number of row ranges.
+void centroid_plan(int64_t n, int64_t k, int num_cus, int* n_rr);
+hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_t n, int64_t k,
+                                    int d, int n_rr, double* part_sums, int64_t* part_counts,
+                                    double* sums, int64_t* counts, hipStream_t s);
+hipError_t launch_centroid_finalize(const double* sums, const int64_t* counts, const float* prev_c,
+                                    int64_t k, int d, float* new_c, uint8_t* has_members,
+                                    hipStream_t s);
+
+}  // namespace ic

@@ -1,0 +1,309 @@
+// HBM-bound reductions that follow the assignment: per-image bag-of-words histograms and k-means
+// centroid sums.  Both are deterministic and use no atomic instruction at all: every memory word
+// has exactly one writer between two barriers.
+//
+// What they replace in the reference (paths relative to the reference tree):
+//   np.histogram(code, bins=range(0, K+1))[0] + L1 normalisation   model/features.py:1174-1181
+//   scipy _vq.update_cluster_means inside kmeans2                  vision/facerec/face_indexing.py:158
+#include "ic_internal.h"
+
+namespace ic {
+
+// ---------------------------------------------------------------------------------------------
+// Histogram.  One workgroup per (image, bin range).  The image's codes are taken in chunks of up
+// to 4096: a chunk is sorted in LDS (bitonic network), so equal codes form runs; the thread on a
+// run's first element subtracts its position from that code's bin, and after a barrier the thread
+// on the run's last element adds position + 1.  A bin is touched by one thread per pass.
+constexpr int kHistThreads = 256;
+constexpr int kSortChunk = 4096;
+constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB + 16 KiB sort buffer of LDS
+constexpr unsigned kNoCode = 0xFFFFFFFFu;
+
+__device__ __forceinline__ double block_sum(double v, double* red /*[kHistThreads/64]*/) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < kHistThreads / 64; ++w) t += red[w];
+  return t;
+}
+
+__device__ __forceinline__ double hist_transform(double c, int norm_mode, double power) {
+  if (norm_mode != IC_NORM_POWER_L2) return c;
+  if (power == 0.5) return sqrt(c);
+  return c == 0.0 ? 0.0 : pow(c, power);
+}
+
+// scale factor applied to the transformed counts of one row, from the row's reductions
+__device__ __forceinline__ double hist_scale(int norm_mode, double sum, double sumsq) {
+  if (norm_mode == IC_NORM_L1) return 1.0 / (sum != 0.0 ? sum : 1.0);
+  if (norm_mode == IC_NORM_L2 || norm_mode == IC_NORM_POWER_L2) {
+    const double nrm = sqrt(sumsq);
+    return nrm != 0.0 ? nrm : 1.0;  // divisor in these modes
+  }
+  return 1.0;
+}
+
+__global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict__ codes,
+                                                       const int64_t* __restrict__ offsets,
+                                                       int64_t k, int bins_per_wg, int norm_mode,
+                                                       double power, int fused_norm,
+                                                       double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned hsm[];
+  __shared__ double red[kHistThreads / 64];
+  const int tid = threadIdx.x;
+  const int64_t img = blockIdx.x;
+  const int64_t bin0 = (int64_t)blockIdx.y * bins_per_wg;
+  int64_t nb64 = k - bin0;
+  if (nb64 > bins_per_wg) nb64 = bins_per_wg;
+  const unsigned nb = (unsigned)nb64;
+  unsigned* hist = hsm;
+  unsigned* buf = hsm + bins_per_wg;
+
+  for (unsigned b = tid; b < nb; b += kHistThreads) hist[b] = 0;
+  const int64_t beg = offsets[img], end = offsets[img + 1];
+
+  for (int64_t base = beg; base < end; base += kSortChunk) {
+    const int64_t left = end - base;
+    const int cnt = left < kSortChunk ? (int)left : kSortChunk;
+    int P = 2 * kHistThreads;
+    while (P < cnt) P <<= 1;
+    __syncthreads();
+    for (int p = tid; p < P; p += kHistThreads) {
+      unsigned v = kNoCode;
+      if (p < cnt) {
+        const int64_t c = (int64_t)codes[base + p] - bin0;
+        if (c >= 0 && c < (int64_t)nb) v = (unsigned)c;
+      }
+      buf[p] = v;
+    }
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        for (int t = tid; t < P / 2; t += kHistThreads) {
+          const int pos = 2 * t - (t & (stride - 1));
+          const unsigned a = buf[pos], b = buf[pos + stride];
+          const bool up = (pos & size) == 0;
+          if ((a > b) == up) {
+            buf[pos] = b;
+            buf[pos + stride] = a;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += kHistThreads) {
+      const unsigned v = buf[p];
+      if (v != kNoCode && (p == 0 || buf[p - 1] != v)) hist[v] -= (unsigned)p;
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += kHistThreads) {
+      const unsigned v = buf[p];
+      if (v != kNoCode && (p == P - 1 || buf[p + 1] != v)) hist[v] += (unsigned)(p + 1);
+    }
+  }
+  __syncthreads();
+
+  double* orow = out + img * k + bin0;
+  if (!fused_norm) {  // raw counts; k_hist_normalise finishes rows that span several workgroups
+    for (unsigned b = tid; b < nb; b += kHistThreads) orow[b] = (double)hist[b];
+    return;
+  }
+  double s = 0.0, s2 = 0.0;
+  if (norm_mode != IC_NORM_NONE) {
+    for (unsigned b = tid; b < nb; b += kHistThreads) {
+      const double y = hist_transform((double)hist[b], norm_mode, power);
+      s += y;
+      s2 += y * y;
+    }
+    s = block_sum(s, red);
+    s2 = block_sum(s2, red);
+  }
+  const double f = hist_scale(norm_mode, s, s2);
+  for (unsigned b = tid; b < nb; b += kHistThreads) {
+    const double y = hist_transform((double)hist[b], norm_mode, power);
+    orow[b] = norm_mode == IC_NORM_L1 ? y * f : (norm_mode == IC_NORM_NONE ? y : y / f);
+  }
+}
+
+// In-place normalisation of rows of raw counts (rows wider than one workgroup's bin range).
+__global__ __launch_bounds__(kHistThreads) void k_hist_normalise(int64_t k, int norm_mode,
+                                                                 double power,
+                                                                 double* __restrict__ out) {
+  __shared__ double red[kHistThreads / 64];
+  double* row = out + (int64_t)blockIdx.x * k;
+  double s = 0.0, s2 = 0.0;
+  for (int64_t b = threadIdx.x; b < k; b += kHistThreads) {
+    const double y = hist_transform(row[b], norm_mode, power);
+    s += y;
+    s2 += y * y;
+  }
+  s = block_sum(s, red);
+  s2 = block_sum(s2, red);
+  const double f = hist_scale(norm_mode, s, s2);
+  for (int64_t b = threadIdx.x; b < k; b += kHistThreads) {
+    const double y = hist_transform(row[b], norm_mode, power);
+    row[b] = norm_mode == IC_NORM_L1 ? y * f : y / f;
+  }
+}
+
+hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
+                       int norm_mode, double power, double* out, hipStream_t s) {
+  if (n_img <= 0) return hipSuccess;
+  const int bins_per_wg = k < kHistMaxBins ? (int)k : kHistMaxBins;
+  const int64_t n_ranges = (k + bins_per_wg - 1) / bins_per_wg;
+  if (n_img > 0x7fffffffLL || n_ranges > 65535) return hipErrorInvalidValue;
+  const int lds = (bins_per_wg + kSortChunk) * 4;
+  // per device and cheap, so it is simply repeated on every call
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  const int fused = n_ranges == 1 ? 1 : 0;
+  hipLaunchKernelGGL(k_hist, dim3((unsigned)n_img, (unsigned)n_ranges), dim3(kHistThreads), lds, s,
+                     codes, offsets, k, bins_per_wg, norm_mode, power, fused, out);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (!fused && norm_mode != IC_NORM_NONE) {
+    hipLaunchKernelGGL(k_hist_normalise, dim3((unsigned)n_img), dim3(kHistThreads), 0, s, k,
+                       norm_mode, power, out);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Centroid sums.  Workgroup (cr, rr) owns clusters [64 cr, 64 cr + 64) over row range rr and keeps
+// their float64 sums in LDS.  Wave w of the workgroup owns the clusters with (cluster & 3) == w: it
+// scans the range's codes 64 at a time, and for every row of one of its clusters adds the row into
+// that cluster's LDS sum (lane l adds components 2l, 2l+1).  Rows are visited in ascending order
+// and a cluster has one owner, so the summation order is fixed.  Row ranges are then added in
+// ascending order by k_centroid_reduce.
+constexpr int kCR = 64;
+constexpr int kCentThreads = 256;
+
+__global__ __launch_bounds__(kCentThreads) void k_centroid_partials(
+    const float* __restrict__ X, const int32_t* __restrict__ codes, int64_t n, int64_t k, int d,
+    int64_t rows_per_range, double* __restrict__ psums, int64_t* __restrict__ pcounts) {
+  __shared__ __attribute__((aligned(16))) double sums[kCR][kD];
+  __shared__ long long cnt[kCR];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t c0 = (int64_t)blockIdx.x * kCR;
+  const int64_t rr = blockIdx.y;
+  const int64_t rbeg = rr * rows_per_range;
+  int64_t rend = rbeg + rows_per_range;
+  if (rend > n) rend = n;
+
+  for (int t = threadIdx.x; t < kCR * kD; t += kCentThreads) (&sums[0][0])[t] = 0.0;
+  if (threadIdx.x < kCR) cnt[threadIdx.x] = 0;
+  __syncthreads();
+
+  const int c2 = 2 * lane;
+  for (int64_t base = rbeg; base < rend; base += 64) {
+    const int64_t r = base + lane;
+    int lc = -1;
+    if (r < rend) {
+      const int64_t c = (int64_t)codes[r] - c0;
+      if (c >= 0 && c < kCR && (c & 3) == wave) lc = (int)c;
+    }
+    unsigned long long m = __ballot(lc >= 0);
+    while (m) {
+      const int e = __builtin_ctzll(m);
+      m &= m - 1;
+      const int cl = __builtin_amdgcn_readlane(lc, e);
+      const float* xrow = X + (base + e) * d;
+      double a0 = 0.0, a1 = 0.0;
+      if (c2 < d) a0 = (double)xrow[c2];
+      if (c2 + 1 < d) a1 = (double)xrow[c2 + 1];
+      sums[cl][c2] += a0;
+      sums[cl][c2 + 1] += a1;
+      if (lane == 0) cnt[cl] += 1;
+    }
+  }
+  __syncthreads();
+
+  int64_t ncl = k - c0;
+  if (ncl > kCR) ncl = kCR;
+  double* ps = psums + (rr * k + c0) * d;
+  for (int t = threadIdx.x; t < (int)ncl * d; t += kCentThreads) ps[t] = sums[t / d][t % d];
+  if (threadIdx.x < ncl) pcounts[rr * k + c0 + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_centroid_reduce(const double* __restrict__ psums,
+                                                         const int64_t* __restrict__ pcounts,
+                                                         int64_t kd, int64_t k, int n_rr,
+                                                         double* __restrict__ sums,
+                                                         int64_t* __restrict__ counts) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < kd; t += (int64_t)gridDim.x * 256) {
+    double a = 0.0;
+    for (int r = 0; r < n_rr; ++r) a += psums[(int64_t)r * kd + t];
+    sums[t] = a;
+    if (t < k) {
+      int64_t c = 0;
+      for (int r = 0; r < n_rr; ++r) c += pcounts[(int64_t)r * k + t];
+      counts[t] = c;
+    }
+  }
+}
+
+void centroid_plan(int64_t n, int64_t k, int num_cus, int* n_rr) {
+  const int64_t n_cr = (k + kCR - 1) / kCR;
+  int64_t rr = (4LL * num_cus + n_cr - 1) / n_cr;
+  const int64_t max_rr = (n + 4095) / 4096;
+  if (rr > max_rr) rr = max_rr;
+  if (rr > 65535) rr = 65535;
+  if (rr < 1) rr = 1;
+  *n_rr = (int)rr;
+}
+
+hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_t n, int64_t k,
+                                    int d, int n_rr, double* part_sums, int64_t* part_counts,
+                                    double* sums, int64_t* counts, hipStream_t s) {
+  const int64_t n_cr = (k + kCR - 1) / kCR;
+  if (n_cr > 0x7fffffffLL) return hipErrorInvalidValue;
+  int64_t rows_per = (n + n_rr - 1) / n_rr;
+  rows_per = (rows_per + 63) / 64 * 64;
+  if (rows_per < 64) rows_per = 64;
+  double* ps = n_rr == 1 ? sums : part_sums;
+  int64_t* pc = n_rr == 1 ? counts : part_counts;
+  hipLaunchKernelGGL(k_centroid_partials, dim3((unsigned)n_cr, (unsigned)n_rr), dim3(kCentThreads),
+                     0, s, x, codes, n, k, d, rows_per, ps, pc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || n_rr == 1) return e;
+  const int64_t kd = k * d;
+  int64_t grid = (kd + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_centroid_reduce, dim3((unsigned)grid), dim3(256), 0, s, part_sums,
+                     part_counts, kd, k, n_rr, sums, counts);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_centroid_finalize(const double* __restrict__ sums,
+                                                           const int64_t* __restrict__ counts,
+                                                           const float* __restrict__ prev,
+                                                           int64_t k, int d, float* __restrict__ out,
+                                                           uint8_t* __restrict__ has_members) {
+  const int64_t kd = k * d;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < kd; t += (int64_t)gridDim.x * 256) {
+    const int64_t j = t / d;
+    const int64_t c = counts[j];
+    out[t] = c != 0 ? (float)(sums[t] / (double)c) : prev[t];
+    if (has_members && t % d == 0) has_members[j] = c != 0 ? 1 : 0;
+  }
+}
+
+hipError_t launch_centroid_finalize(const double* sums, const int64_t* counts, const float* prev_c,
+                                    int64_t k, int d, float* new_c, uint8_t* has_members,
+                                    hipStream_t s) {
+  int64_t grid = (k * d + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_centroid_finalize, dim3((unsigned)grid), dim3(256), 0, s, sums, counts,
+                     prev_c, k, d, new_c, has_members);
+  return hipGetLastError();
+}
+
+}  // namespace ic

@@ -1,0 +1,93 @@
+"""Device selection and device-resident codebooks.
+
+The reference keeps its vocabulary as a float64 numpy array on the model object
+(model/features.py:1335-1341, :1259) and hands it to scipy on every call.  Here the float32 copy
+the kernels read stays in HBM between calls; it is looked up by a fingerprint of the host array.
+"""
+import os
+import threading
+import zlib
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def default_device():
+    """cuda:<IC_AMD_DEVICE | LOCAL_RANK | current device>.  Raises without a GPU."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: image_classification_amd has no CPU path")
+    for var in ("IC_AMD_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v != "":
+            return torch.device("cuda", int(v) % torch.cuda.device_count())
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class ResidentCodebook(object):
+    """float32 codebook [K, D] in HBM together with its squared row norms."""
+
+    def __init__(self, codebook, device=None):
+        device = device or default_device()
+        self.c = ops.as_device_f32(codebook, device)
+        if self.c.dim() != 2:
+            raise ValueError("codebook must be 2-D")
+        self.sqnorm = ops.row_sqnorm(self.c)
+        self.device = self.c.device
+
+    @property
+    def shape(self):
+        return tuple(self.c.shape)
+
+
+def _fingerprint(a):
+    """Cheap content fingerprint: identity, layout and a CRC over a strided sample of rows."""
+    flat = a.reshape(a.shape[0], -1)
+    step = max(1, flat.shape[0] // 64)
+    sample = np.ascontiguousarray(flat[::step])
+    return (a.__array_interface__["data"][0], a.shape, a.dtype.str,
+            zlib.crc32(sample.view(np.uint8)), zlib.crc32(np.ascontiguousarray(flat[-1:]).view(np.uint8)))
+
+
+_cache = {}
+_cache_lock = threading.Lock()
+_CACHE_MAX = 8
+
+
+def resident(codebook, device=None):
+    """ResidentCodebook for a host array, reusing the device copy while the array is unchanged.
+
+    The fingerprint samples 64 rows; code that edits other rows of a codebook in place must call
+    `forget(codebook)` (the reference never mutates a trained vocabulary).
+    """
+    if isinstance(codebook, ResidentCodebook):
+        return codebook
+    device = device or default_device()
+    if isinstance(codebook, torch.Tensor):
+        return ResidentCodebook(codebook, device)
+    a = np.asarray(codebook)
+    if a.ndim != 2:
+        raise ValueError("codebook must be 2-D, got shape %s" % (a.shape,))
+    key = (os.getpid(), str(device)) + _fingerprint(a)
+    with _cache_lock:
+        hit = _cache.get(key)
+    if hit is not None:
+        return hit
+    rc = ResidentCodebook(a, device)
+    with _cache_lock:
+        if len(_cache) >= _CACHE_MAX:
+            _cache.pop(next(iter(_cache)))
+        _cache[key] = rc
+    return rc
+
+
+def forget(codebook=None):
+    """Drop cached device copies (all of them, or the one of this array)."""
+    with _cache_lock:
+        if codebook is None:
+            _cache.clear()
+            return
+        ptr = np.asarray(codebook).__array_interface__["data"][0]
+        for k in [k for k in _cache if k[2] == ptr]:
+            _cache.pop(k)

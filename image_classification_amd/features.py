@@ -1,0 +1,245 @@
+"""Bag-of-words quantisation with the reference's class and method names.
+
+Mirrors `BagOfWords` (model/features.py:1125-1284) and `Vocabulary` (model/features.py:1329-1391):
+same constructor arguments, `train` / `extract` return `(image_descs, hists)` with `hists` a
+float64 array [n_images, vocabsize], images whose `descriptors` is None give an all-zero row, and
+the histogram is L1-normalised exactly as `hist * (1.0 / (sum or 1))` (model/features.py:1174-1181).
+
+What differs from the reference is only how the work is issued: the reference calls scipy's `vq`
+once per image in a Python loop (model/features.py:1164-1169) and builds each histogram with
+np.histogram; here all descriptors of a call are concatenated, one device call assigns them and
+one device call builds every histogram.
+
+`norm` is an extension: 'l1' is the reference's normalisation, 'l2', 'power_l2' and 'none' are
+additional modes with no counterpart in the reference.
+"""
+import os
+import pickle
+
+import numpy as np
+
+from .backend import default_backend
+from .clustering import kmeans_fit
+from .imagedesc import ImageDesc
+
+__all__ = ["BagOfWords", "Vocabulary"]
+
+
+class Vocabulary(object):
+    """Vocabulary trainer.
+
+    The reference writes the descriptors to an OpenCV-XML + raw float32 file pair and runs an
+    external `vocab_kms` binary whose source is not part of the reference tree
+    (model/features.py:1367-1378, vision/utils/bovw_functions.py:111-119).  This class trains on
+    the device instead, with the Lloyd semantics of the only k-means whose code the reference
+    does show (scipy kmeans2, minit='points'; vision/facerec/face_indexing.py:158).  Like the
+    reference's `_read_vocab` (model/features.py:1335-1341) it returns a float64 array.
+    """
+
+    def __init__(self, vocab_size, iterations=20, seed=None, backend=None):
+        self.vocab_size = vocab_size
+        self.iterations = iterations
+        self.seed = seed
+        self._backend = backend
+        self.vocab = None
+
+    def train(self, feats):
+        feats = np.asarray(feats)
+        # same guard as vocab_kms's wrapper (vision/utils/bovw_functions.py:116-117)
+        assert self.vocab_size <= feats.shape[0], \
+            "Number of clusters should be less than number of descriptors"
+        self.dim = feats.shape[1]
+        centers, _ = kmeans_fit(feats.astype(np.float32, copy=False), self.vocab_size,
+                                iters=self.iterations, minit="points", rng=self.seed,
+                                backend=self._backend)
+        self.vocab = centers.astype(np.float64)
+        return self.vocab
+
+    def save_to_file(self, file_path):
+        assert self.vocab is not None, "Vocabulary is missing"
+        with open(file_path, "wb") as f:
+            np.save(f, self.vocab)
+
+    @classmethod
+    def load_from_file(cls, file_path):
+        with open(file_path, "rb") as f:
+            vocab = np.load(f)
+        obj = cls(len(vocab))
+        obj.vocab = vocab
+        return obj
+
+
+class BagOfWords(object):
+
+    def __init__(self, feat_ext, vocabsize=None, vocab=None, projection=None, norm="l1",
+                 power=0.5, backend=None):
+        self.feat_ext = feat_ext
+        assert hasattr(feat_ext, "extract")
+        self.projection = projection
+        if self.projection:
+            assert hasattr(projection, "train")
+            assert hasattr(projection, "project")
+        if vocab is not None:
+            self.vocabsize = len(vocab)
+        else:
+            assert vocabsize, "Vocabsize required for training"
+            self.vocabsize = vocabsize
+        self.vocab = vocab
+        self.norm = norm
+        self.power = power
+        self._backend = backend
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _b(self):
+        return getattr(self, "_backend", None) or default_backend()
+
+    def _learn_projection(self, all_feats):
+        self.projection.train(all_feats)
+
+    def _project(self, image_descs):
+        projected_descs = []
+        for i in image_descs:
+            if i.descriptors is not None:
+                proj_feats = self.projection.project(i.descriptors)
+                desc = ImageDesc(i.cv_keypoints, proj_feats)
+            else:
+                desc = ImageDesc(i.cv_keypoints, None)
+            projected_descs.append(desc)
+        return projected_descs
+
+    def _learn_vocab(self, all_feats):
+        self._vocab_trainer = Vocabulary(self.vocabsize, backend=getattr(self, "_backend", None))
+        self.vocab = self._vocab_trainer.train(all_feats)
+        return self.vocab
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def _assign_all(self, image_descs):
+        """One device call for every descriptor of every image.
+
+        Returns (codes int32 device tensor [total], offsets int64 numpy [n_img + 1]).
+        """
+        b = self._b()
+        rows = [0]
+        parts = []
+        for idesc in image_descs:
+            n = 0
+            if idesc.descriptors is not None:
+                n = idesc.descriptors.shape[0]
+                if n:
+                    parts.append(np.asarray(idesc.descriptors, dtype=np.float32))
+            rows.append(rows[-1] + n)
+        offsets = np.asarray(rows, dtype=np.int64)
+        if not parts:
+            return b.i32(np.empty(0, dtype=np.int32)), offsets
+        allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        codes, _ = b.assign_top1(b.f32(allx), b.codebook(self.vocab), want_dist=False)
+        return codes, offsets
+
+    def _quantize(self, image_descs):
+        codes, offsets = self._assign_all(image_descs)
+        if type(self)._build_histogram is BagOfWords._build_histogram:
+            b = self._b()
+            hists = b.hist(codes, b.i64(offsets), len(self.vocab), self.norm, self.power)
+            return image_descs, hists.cpu().numpy()
+        # a subclass builds its own histogram from per-image code lists (SpatialBagOfWords does,
+        # model/features.py:1298-1308): hand it what the reference hands it
+        host = codes.cpu().numpy()
+        codebooks = []
+        for i, idesc in enumerate(image_descs):
+            if idesc.descriptors is not None:
+                codebooks.append(host[offsets[i]:offsets[i + 1]])
+            else:
+                codebooks.append([])
+        return image_descs, self._build_histogram(image_descs, codebooks)
+
+    def _build_histogram(self, image_descs, codebooks):
+        b = self._b()
+        rows = [0]
+        parts = []
+        for code in codebooks:
+            code = np.asarray(code, dtype=np.int32).reshape(-1)
+            parts.append(code)
+            rows.append(rows[-1] + code.shape[0])
+        allc = np.concatenate(parts) if parts else np.empty(0, dtype=np.int32)
+        if len(codebooks) == 0:
+            return np.asarray([])
+        hists = b.hist(b.i32(allc), b.i64(np.asarray(rows, dtype=np.int64)), len(self.vocab),
+                       self.norm, self.power)
+        return hists.cpu().numpy()
+
+    def _feature_extract(self, image_list):
+        results = self.feat_ext.extract(image_list)
+        return [ImageDesc(*r) for r in results]
+
+    def _merge_descs_to_feats(self, image_descs):
+        return np.concatenate([i.descriptors for i in image_descs if i.descriptors is not None])
+
+    def train(self, image_list):
+        image_descs = self._feature_extract(image_list)
+        if self.projection:
+            all_feats = self._merge_descs_to_feats(image_descs)
+            self._learn_projection(all_feats)
+            image_descs = self._project(image_descs)
+        if self.vocab is None:
+            all_feats = self._merge_descs_to_feats(image_descs)
+            self.vocab = self._learn_vocab(all_feats)
+        return self._quantize(image_descs)
+
+    def extract(self, image_list):
+        image_descs = self._feature_extract(image_list)
+        if self.projection:
+            image_descs = self._project(image_descs)
+        return self._quantize(image_descs)
+
+    # -- model directory (vocab.npy is the codebook's on-disk format, model/features.py:1218-1268)
+    def save_to_dir(self, model_dir):
+        assert self.vocab is not None, "vocab is not set"
+        if not os.path.isdir(model_dir):
+            os.makedirs(model_dir)
+        class_dict = {}
+        if self.projection:
+            self.projection.save_to_file(self._proj_path(model_dir))
+            class_dict["project"] = self.projection.__class__
+        np.save(self._vocab_path(model_dir), self.vocab)
+        self.feat_ext.save_to_file(self._feat_path(model_dir))
+        class_dict["feat_ext"] = self.feat_ext.__class__
+        with open(self._class_path(model_dir), "wb") as f:
+            pickle.dump(class_dict, f)
+
+    @staticmethod
+    def get_state(model_dir):
+        cls = BagOfWords
+        with open(cls._class_path(model_dir), "rb") as f:
+            class_dict = pickle.load(f)
+        feat_ext = class_dict["feat_ext"].load_from_file(cls._feat_path(model_dir))
+        projection = None
+        if "project" in class_dict:
+            projection = class_dict["project"].load_from_file(cls._proj_path(model_dir))
+        vocab = np.load(cls._vocab_path(model_dir))
+        return dict(vocab=vocab, vocabsize=len(vocab), feat_ext=feat_ext, projection=projection)
+
+    @classmethod
+    def load_from_dir(cls, model_dir):
+        state = cls.get_state(model_dir)
+        obj = cls.__new__(cls)
+        vars(obj).update(state)
+        obj.norm = "l1"
+        obj.power = 0.5
+        obj._backend = None
+        return obj
+
+    @staticmethod
+    def _class_path(model_dir):
+        return os.path.join(model_dir, "class_file")
+
+    @staticmethod
+    def _proj_path(model_dir):
+        return os.path.join(model_dir, "project")
+
+    @staticmethod
+    def _vocab_path(model_dir):
+        return os.path.join(model_dir, "vocab.npy")
+
+    @staticmethod
+    def _feat_path(model_dir):
+        return os.path.join(model_dir, "feat_ext")

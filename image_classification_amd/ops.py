@@ -1,0 +1,178 @@
+"""Device-level operators: torch CUDA tensors in, torch CUDA tensors out, one C-ABI call each.
+
+torch is used for device memory and streams only; all arithmetic happens in libic_hip.so.  The
+numpy-in / numpy-out mirrors of the reference's call sites (vq.py, features.py, classifiers.py,
+robust_matching.py, scene_functions.py) are thin layers over these functions.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+TOP2_REC_DTYPE = np.dtype([("d1", "<f4"), ("i1", "<i4"), ("d2", "<f4"), ("i2", "<i4")])
+
+
+def _dev_index(t):
+    if not t.is_cuda:
+        raise ValueError("expected a CUDA tensor (there is no CPU path)")
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _stream_ptr(device_index):
+    return ctypes.c_void_p(torch.cuda.current_stream(device_index).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check_2d_f32(t, name):
+    if t.dim() != 2:
+        raise ValueError("%s must be 2-D, got shape %s" % (name, tuple(t.shape)))
+    if t.dtype != torch.float32:
+        raise ValueError("%s must be float32 on the device, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be C-contiguous" % name)
+
+
+def as_device_f32(a, device):
+    """numpy (any float dtype) or torch tensor -> contiguous float32 CUDA tensor on `device`."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float32).contiguous()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return torch.from_numpy(a).to(device)
+
+
+def row_sqnorm(x):
+    _check_2d_f32(x, "x")
+    dev = _dev_index(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    rc = _lib.load().ic_row_sqnorm(_lib.handle(dev), _ptr(x), x.shape[0], x.shape[1], _ptr(out),
+                                   _stream_ptr(dev))
+    _lib.check(rc, "ic_row_sqnorm")
+    return out
+
+
+def _check_pair(x, c):
+    _check_2d_f32(x, "x")
+    _check_2d_f32(c, "codebook")
+    if x.shape[1] != c.shape[1]:
+        raise ValueError("dimension mismatch: x has %d columns, codebook %d" % (x.shape[1], c.shape[1]))
+    if c.shape[0] < 1:
+        raise ValueError("empty codebook")
+    if x.device != c.device:
+        raise ValueError("x and codebook live on different devices")
+
+
+def assign_top1(x, c, c_sqnorm=None, want_dist=True):
+    """idx[i] = argmin_j |x_i - c_j| (lowest j on ties), dist[i] = that Euclidean distance."""
+    _check_pair(x, c)
+    dev = _dev_index(x)
+    n = x.shape[0]
+    idx = torch.empty(n, dtype=torch.int32, device=x.device)
+    dist = torch.empty(n, dtype=torch.float32, device=x.device) if want_dist else None
+    rc = _lib.load().ic_assign_top1(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
+                                    _ptr(c_sqnorm), _ptr(idx), _ptr(dist), _stream_ptr(dev))
+    _lib.check(rc, "ic_assign_top1")
+    return idx, dist
+
+
+def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True):
+    """Two nearest rows of c per row of x, ascending (distance, index), and the ratio-test mask."""
+    _check_pair(x, c)
+    dev = _dev_index(x)
+    n = x.shape[0]
+    i1 = torch.empty(n, dtype=torch.int32, device=x.device)
+    i2 = torch.empty(n, dtype=torch.int32, device=x.device)
+    d1 = torch.empty(n, dtype=torch.float32, device=x.device)
+    d2 = torch.empty(n, dtype=torch.float32, device=x.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None
+    rc = _lib.load().ic_assign_top2(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
+                                    _ptr(c_sqnorm), _ptr(i1), _ptr(d1), _ptr(i2), _ptr(d2),
+                                    float(ratio), _ptr(mask), _stream_ptr(dev))
+    _lib.check(rc, "ic_assign_top2")
+    return i1, d1, i2, d2, mask
+
+
+def assign_top2_rec(x, c, c_sqnorm=None):
+    """Same search, packed as [n, 4] int32 words = ic_top2_rec {d1, i1, d2, i2} per row."""
+    _check_pair(x, c)
+    dev = _dev_index(x)
+    n = x.shape[0]
+    rec = torch.empty((n, 4), dtype=torch.int32, device=x.device)
+    rc = _lib.load().ic_assign_top2_rec(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0],
+                                        x.shape[1], _ptr(c_sqnorm), _ptr(rec), _stream_ptr(dev))
+    _lib.check(rc, "ic_assign_top2_rec")
+    return rec
+
+
+def top2_merge(gathered, shard_base, ratio=0.8, want_mask=True):
+    """gathered: [n_shards, n, 4] int32 (ic_top2_rec words); shard_base: sequence of ints."""
+    if gathered.dim() != 3 or gathered.shape[2] != 4 or gathered.dtype != torch.int32:
+        raise ValueError("gathered must be int32 [n_shards, n, 4]")
+    if not gathered.is_contiguous():
+        raise ValueError("gathered must be contiguous")
+    dev = _dev_index(gathered)
+    n_shards, n = gathered.shape[0], gathered.shape[1]
+    if len(shard_base) != n_shards:
+        raise ValueError("need one shard base per shard")
+    base = (ctypes.c_int64 * n_shards)(*[int(b) for b in shard_base])
+    i1 = torch.empty(n, dtype=torch.int64, device=gathered.device)
+    i2 = torch.empty(n, dtype=torch.int64, device=gathered.device)
+    d1 = torch.empty(n, dtype=torch.float32, device=gathered.device)
+    d2 = torch.empty(n, dtype=torch.float32, device=gathered.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=gathered.device) if want_mask else None
+    rc = _lib.load().ic_top2_merge(_lib.handle(dev), _ptr(gathered), n_shards, n, base, _ptr(i1),
+                                   _ptr(d1), _ptr(i2), _ptr(d2), float(ratio), _ptr(mask),
+                                   _stream_ptr(dev))
+    _lib.check(rc, "ic_top2_merge")
+    return i1, d1, i2, d2, mask
+
+
+def hist(codes, offsets, k, norm="l1", power=0.5):
+    """codes int32 [total], offsets int64 [n_img+1] -> float64 [n_img, k] normalised histograms."""
+    if codes.dtype != torch.int32 or offsets.dtype != torch.int64:
+        raise ValueError("codes must be int32 and offsets int64")
+    if norm not in _lib.NORM_MODES:
+        raise ValueError("norm must be one of %s" % sorted(_lib.NORM_MODES))
+    dev = _dev_index(offsets)
+    n_img = offsets.shape[0] - 1
+    out = torch.empty((n_img, int(k)), dtype=torch.float64, device=offsets.device)
+    rc = _lib.load().ic_hist(_lib.handle(dev), _ptr(codes.contiguous()), _ptr(offsets.contiguous()),
+                             n_img, int(k), _lib.NORM_MODES[norm], float(power), _ptr(out),
+                             _stream_ptr(dev))
+    _lib.check(rc, "ic_hist")
+    return out
+
+
+def centroid_partials(x, codes, k):
+    """sums float64 [k, d] and counts int64 [k] of the rows of x grouped by code."""
+    _check_2d_f32(x, "x")
+    if codes.dtype != torch.int32 or codes.shape[0] != x.shape[0]:
+        raise ValueError("codes must be int32 with one entry per row of x")
+    dev = _dev_index(x)
+    sums = torch.empty((int(k), x.shape[1]), dtype=torch.float64, device=x.device)
+    counts = torch.empty(int(k), dtype=torch.int64, device=x.device)
+    rc = _lib.load().ic_centroid_partials(_lib.handle(dev), _ptr(x), _ptr(codes.contiguous()),
+                                          x.shape[0], int(k), x.shape[1], _ptr(sums), _ptr(counts),
+                                          _stream_ptr(dev))
+    _lib.check(rc, "ic_centroid_partials")
+    return sums, counts
+
+
+def centroid_finalize(sums, counts, prev_c):
+    """new_c = sums / counts, or prev_c where a cluster is empty; also returns has_members."""
+    _check_2d_f32(prev_c, "prev_c")
+    if sums.dtype != torch.float64 or counts.dtype != torch.int64:
+        raise ValueError("sums must be float64 and counts int64")
+    dev = _dev_index(prev_c)
+    k, d = prev_c.shape
+    new_c = torch.empty_like(prev_c)
+    has = torch.empty(k, dtype=torch.uint8, device=prev_c.device)
+    rc = _lib.load().ic_centroid_finalize(_lib.handle(dev), _ptr(sums.contiguous()),
+                                          _ptr(counts.contiguous()), _ptr(prev_c), k, d,
+                                          _ptr(new_c), _ptr(has), _stream_ptr(dev))
+    _lib.check(rc, "ic_centroid_finalize")
+    return new_c, has

@@ -1,0 +1,61 @@
+"""Drop-in for the two scipy.cluster.vq functions the reference calls.
+
+`vq(obs, code_book)`   replaces scipy.cluster.vq.vq at model/features.py:1166 and
+                       vision/facerec/face_indexing.py:141
+`kmeans2(data, k, ...)` replaces scipy.cluster.vq.kmeans2 at vision/facerec/face_indexing.py:158
+
+Same argument meaning, return types and error behaviour; the arithmetic runs in float32 on the
+GPU (scipy promotes to the common dtype of its arguments, float64 for the reference's float64
+vocabulary), so distances agree to float32 rounding and indices wherever the best and second
+best codeword are not within float32 rounding of each other.
+"""
+import numpy as np
+
+from .backend import default_backend
+from .clustering import kmeans_fit
+
+
+def _as_2d(a, name):
+    a = np.asarray(a)
+    if a.ndim == 1:
+        a = a[:, None]
+    if a.ndim != 2:
+        raise ValueError("%s must be 1-D or 2-D" % name)
+    return a
+
+
+def vq(obs, code_book, check_finite=True, backend=None):
+    """(code int32 [M], dist [M]) -- index of and Euclidean distance to the nearest code."""
+    obs_a = np.asarray(obs)
+    cb_a = np.asarray(code_book)
+    if obs_a.ndim != cb_a.ndim:
+        raise ValueError("Observation and code_book should have the same rank")
+    obs_a = _as_2d(obs_a, "obs")
+    cb_a = _as_2d(cb_a, "code_book")
+    if obs_a.shape[1] != cb_a.shape[1]:
+        raise ValueError("Code book(%d) and obs(%d) should have the same number of features "
+                         "(e.g. columns)" % (cb_a.shape[1], obs_a.shape[1]))
+    if check_finite and not (np.isfinite(obs_a).all() and np.isfinite(cb_a).all()):
+        raise ValueError("array must not contain infs or NaNs")
+    ct = np.result_type(obs_a.dtype, cb_a.dtype)
+    if ct.kind != "f":
+        ct = np.dtype(np.float64)
+    if obs_a.shape[0] == 0:
+        return np.empty(0, dtype=np.int32), np.empty(0, dtype=ct)
+    b = backend or default_backend()
+    idx, dist = b.assign_top1(b.f32(obs_a), b.codebook(cb_a), want_dist=True)
+    return idx.cpu().numpy(), dist.cpu().numpy().astype(ct)
+
+
+def kmeans2(data, k, iter=10, thresh=1e-5, minit="points", missing="warn", check_finite=True,
+            rng=None, seed=None, backend=None):
+    """(codebook, label) with scipy.cluster.vq.kmeans2 semantics ('points' and 'matrix' inits).
+
+    `thresh` is accepted and unused, as in scipy.
+    """
+    data = np.asarray(data)
+    if check_finite and not np.isfinite(data).all():
+        raise ValueError("array must not contain infs or NaNs")
+    if rng is None:
+        rng = seed
+    return kmeans_fit(data, k, iters=iter, minit=minit, missing=missing, rng=rng, backend=backend)

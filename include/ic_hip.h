@@ -1,0 +1,119 @@
+/*
+ * ic_hip.h -- C ABI of libic_hip.so: nearest-codeword / nearest-neighbour search over
+ * local image descriptors on AMD MI355X (gfx950).
+ *
+ * The reference (winkash/image-classification) has no FFI of its own: this path is reached
+ * through numpy-in / numpy-out Python calls into scipy / scikit-learn.  Each entry point below
+ * names the reference call it replaces (path:line relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, otherwise a non-zero code (a hipError_t value, or
+ *     one of the IC_E* codes below); ic_last_error() gives the text for the calling thread's
+ *     last failure on that handle.
+ *   - all array pointers are DEVICE pointers owned by the caller (row-major, contiguous) unless
+ *     a parameter is documented as "host".  The library never frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
+ *     and return; the caller synchronises the stream before reading outputs.
+ *   - a handle owns a grow-only device workspace (partial results, padded norms).  Growing it
+ *     synchronises the device once; calls on one handle are serialised by a mutex, so a handle
+ *     may be shared by threads.  Handles must not cross fork(): create one per process.
+ *   - descriptor dimension d: 1 <= d <= 128 (rows are zero-padded to 128 internally).
+ */
+#ifndef IC_HIP_H
+#define IC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IC_OK 0
+#define IC_EINVAL 10001   /* bad argument (null pointer, negative size, unsupported d, ...) */
+#define IC_ENOMEM 10002   /* workspace allocation failed */
+#define IC_EHANDLE 10003  /* null / destroyed handle */
+
+/* normalisation modes of ic_hist */
+#define IC_NORM_NONE 0     /* raw counts */
+#define IC_NORM_L1 1       /* count * (1.0 / (sum or 1))   -- model/features.py:1178-1179 */
+#define IC_NORM_L2 2       /* count / (sqrt(sum count^2) or 1) */
+#define IC_NORM_POWER_L2 3 /* y = count^power, then y / (sqrt(sum y^2) or 1) */
+
+/* per-row partial result exchanged between shards / K-splits (16 bytes) */
+typedef struct ic_top2_rec {
+  float d1;   /* best distance (Euclidean, not squared) */
+  int32_t i1; /* its index inside the shard, -1 if none */
+  float d2;   /* second best distance */
+  int32_t i2; /* its index inside the shard, -1 if none */
+} ic_top2_rec;
+
+/* Library / handle management.  No counterpart in the reference (scipy/sklearn need none). */
+int ic_version(void);
+int ic_create(int device, void** handle);
+int ic_destroy(void* handle);
+const char* ic_last_error(void* handle); /* handle may be NULL: error of the last failed ic_create */
+
+/* out[i] = sum_j x[i][j]^2.  Replaces the squared-norm terms scipy's _vq.vq and sklearn's
+ * euclidean_distances compute implicitly (model/features.py:1166,
+ * vision/utils/scene_functions.py:391). */
+int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, void* stream);
+
+/* Nearest codeword per row: idx[i] = argmin_j ||x_i - c_j|| (lowest j on ties), dist[i] = that
+ * Euclidean distance.  Replaces scipy.cluster.vq.vq at model/features.py:1166 and
+ * vision/facerec/face_indexing.py:141, and argmin(euclidean_distances(..., squared=True)) at
+ * vision/utils/scene_functions.py:391.
+ *   x [n][d] f32, c [k][d] f32, c_sqnorm [k] f32 or NULL (computed internally),
+ *   idx [n] int32, dist [n] f32 or NULL. */
+int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                   const float* c_sqnorm, int32_t* idx, float* dist, void* stream);
+
+/* Two nearest index rows per search row, ascending (distance, index), plus the ratio test
+ * mask[i] = d1[i] < d2[i] * ratio.  Replaces KNeighborsClassifier.kneighbors(x, 2) at
+ * model/classifiers.py:195-197 as used by model/robust_matching.py:80, and the Python ratio
+ * loop at model/robust_matching.py:81-84.
+ *   i2/d2 may be NULL (top-1 only); mask may be NULL; when k == 1, i2 = -1 and d2 = +inf. */
+int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                   const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2,
+                   float ratio, uint8_t* mask, void* stream);
+
+/* Same search, but the result is written as one ic_top2_rec per row (indices local to this
+ * index shard) for a later ic_top2_merge.  No counterpart in the reference: it exists because
+ * the index side of model/robust_matching.py:73-80 is sharded over GPUs. */
+int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                       const float* c_sqnorm, ic_top2_rec* rec, void* stream);
+
+/* Merge per-shard top-2 records: gathered [n_shards][n] records; shard_base (HOST pointer,
+ * n_shards int64) is added to each shard's local indices.  Order is (distance, global index).
+ * Outputs as ic_assign_top2 but with int64 indices (sklearn returns int64,
+ * model/classifiers.py:196).  i2/d2/mask may be NULL. */
+int ic_top2_merge(void* handle, const ic_top2_rec* gathered, int n_shards, int64_t n,
+                  const int64_t* shard_base, int64_t* i1, float* d1, int64_t* i2, float* d2,
+                  float ratio, uint8_t* mask, void* stream);
+
+/* Per-image bag-of-words histogram.  Replaces np.histogram(code, bins=range(0, K+1))[0] and the
+ * L1 normalisation at model/features.py:1174-1181 (one call for all images instead of the
+ * reference's per-image Python loop).
+ *   codes [offsets[n_img]] int32 (values outside [0,k) are ignored, as np.histogram does),
+ *   offsets [n_img+1] int64 ascending (image i owns codes[offsets[i]:offsets[i+1]]; empty
+ *   images give an all-zero row), out [n_img][k] float64. */
+int ic_hist(void* handle, const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
+            int norm_mode, double power, double* out, void* stream);
+
+/* k-means update step, part 1: sums[j] = sum of rows with codes[i] == j (float64), counts[j] =
+ * number of them.  Replaces scipy's _vq.update_cluster_means inside kmeans2
+ * (vision/facerec/face_indexing.py:158).  Deterministic: fixed summation order, no atomics.
+ *   x [n][d] f32, codes [n] int32 in [0,k), sums [k][d] f64, counts [k] int64. */
+int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int64_t n, int64_t k,
+                         int d, double* sums, int64_t* counts, void* stream);
+
+/* k-means update step, part 2: new_c[j] = sums[j] / counts[j], or prev_c[j] when counts[j] == 0
+ * (scipy kmeans2 missing='warn' keeps the previous centroid, vision/facerec/face_indexing.py:158).
+ *   has_members [k] uint8 or NULL receives counts[j] != 0. */
+int ic_centroid_finalize(void* handle, const double* sums, const int64_t* counts,
+                         const float* prev_c, int64_t k, int d, float* new_c,
+                         uint8_t* has_members, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IC_HIP_H */

@@ -1,0 +1,160 @@
+"""GPU parity of the distance / top-2 kernels against the float64 oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from image_classification_amd import ops
+from image_classification_amd.synthetic import sift_like, surf_like
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (BASELINE north_star): indices equal wherever the oracle's gap to the next candidate
+# exceeds 1e-5 relative; distances within 1e-4 relative.
+DIST_REL = 1e-4
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _run_top2(x, c, ratio=0.8):
+    i1, d1, i2, d2, mask = ops.assign_top2(_dev(x), _dev(c), ratio)
+    torch.cuda.synchronize()
+    return (i1.cpu().numpy(), d1.cpu().numpy(), i2.cpu().numpy(), d2.cpu().numpy(),
+            mask.cpu().numpy().astype(bool))
+
+
+def _check_top2(x, c, ratio=0.8, min_agree=0.9999):
+    i1, d1, i2, d2, mask = _run_top2(x, c, ratio)
+    rd, ri = oracle.topk(x.astype(np.float32), c.astype(np.float32), 3)
+    must1, bad1, agree1 = oracle.check_indices(i1, ri, rd, 0)
+    assert bad1 == 0, "%d of %d well-separated best neighbours differ" % (bad1, must1)
+    assert agree1 >= min_agree
+    if c.shape[0] >= 2:
+        must2, bad2, agree2 = oracle.check_indices(i2, ri, rd, 1)
+        assert bad2 == 0, "%d of %d well-separated second neighbours differ" % (bad2, must2)
+        assert agree2 >= min_agree - 1e-3
+        ok1 = i1 == ri[:, 0]
+        ok2 = i2 == ri[:, 1]
+        assert oracle.check_close(d1[ok1], rd[ok1, 0]) <= DIST_REL
+        assert oracle.check_close(d2[ok2], rd[ok2, 1]) <= DIST_REL
+        # ratio mask: must agree except within 1e-5 relative of the threshold
+        ref_mask = rd[:, 0] < rd[:, 1] * ratio
+        margin = np.abs(rd[:, 0] - rd[:, 1] * ratio) / np.maximum(rd[:, 1], 1e-30)
+        clear = (margin > 1e-5) & ok1 & ok2
+        assert np.array_equal(mask[clear], ref_mask[clear])
+    return agree1
+
+
+@pytest.mark.parametrize("n,k", [(2048, 64), (1000, 1000), (513, 65), (31, 2), (7, 1), (4096, 130)])
+def test_top2_vs_oracle_sift(n, k):
+    x = sift_like(n, seed=11)
+    c = sift_like(k, seed=12)
+    _check_top2(x, c)
+
+
+def test_top2_surf_like_signed_unit_norm():
+    x = surf_like(3000, seed=3)
+    c = surf_like(500, seed=4)
+    _check_top2(x, c)
+
+
+def test_config1_100k_by_1k():
+    # BASELINE config 1 at full size: 100k descriptors vs a 1k-word codebook
+    x = sift_like(100000, seed=1)
+    c = sift_like(1000, seed=2)
+    agree = _check_top2(x, c)
+    assert agree >= 0.9999
+
+
+def test_ties_lowest_index_wins():
+    # duplicated codewords and rounded (integer) data: exact ties; scipy/numpy keep the lowest index
+    x = sift_like(1500, seed=5, rounded=True)
+    c = sift_like(96, seed=6, rounded=True)
+    c2 = np.concatenate([c, c[:40], c[10:20]])  # 40 + 10 duplicated codewords
+    idx, dist = ops.assign_top1(_dev(x), _dev(c2))
+    ref_code, ref_dist = oracle.vq(x, c2)
+    got = idx.cpu().numpy()
+    assert np.array_equal(got, ref_code)
+    assert got.max() < 96  # a duplicate (higher index) never wins
+    assert oracle.check_close(dist.cpu().numpy(), ref_dist) <= DIST_REL
+    # descriptors equal to codewords: distance exactly 0
+    idx2, dist2 = ops.assign_top1(_dev(c[:50]), _dev(c2))
+    assert np.array_equal(idx2.cpu().numpy(), np.arange(50))
+    assert np.all(dist2.cpu().numpy() == 0.0)
+    # top-2 of an exact duplicate pair: (j, j + 96), both at distance 0
+    i1, d1, i2, d2, _ = _run_top2(c[:40], c2)
+    assert np.array_equal(i1, np.arange(40)) and np.array_equal(i2, np.arange(40) + 96)
+    assert np.all(d1 == 0) and np.all(d2 == 0)
+
+
+@pytest.mark.parametrize("d", [64, 36, 100, 1])
+def test_other_dimensions_are_zero_padded(d):
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((700, d)).astype(np.float32) * 10
+    c = rng.standard_normal((90, d)).astype(np.float32) * 10
+    _check_top2(x, c, min_agree=0.999)
+
+
+def test_k_split_large_index_small_query():
+    # few search rows, large index: the grid splits the index and merges the partial top-2
+    x = sift_like(200, seed=21)
+    c = sift_like(60000, n_modes=4096, seed=22)
+    _check_top2(x, c, min_agree=0.995)
+
+
+def test_planted_matches_ratio_mask():
+    rng = np.random.default_rng(7)
+    index = sift_like(800, seed=31)
+    x = sift_like(5000, seed=32)
+    planted = rng.choice(5000, size=250, replace=False)
+    src = rng.integers(0, 800, size=250)
+    x[planted] = index[src] + rng.normal(0, 2.0, size=(250, 128)).astype(np.float32)
+    i1, d1, i2, d2, mask = _run_top2(x, index, 0.8)
+    assert np.array_equal(i1[planted], src)
+    assert mask[planted].all()
+    _check_top2(x, index)
+
+
+def test_top1_matches_top2_and_row_sqnorm():
+    x = sift_like(3000, seed=41)
+    c = sift_like(300, seed=42)
+    xd, cd = _dev(x), _dev(c)
+    idx, dist = ops.assign_top1(xd, cd)
+    i1, d1, _, _, _ = ops.assign_top2(xd, cd)
+    assert torch.equal(idx, i1) and torch.equal(dist, d1)
+    # caller-provided codebook norms give the same result
+    cn = ops.row_sqnorm(cd)
+    idx2, dist2 = ops.assign_top1(xd, cd, cn)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    ref = (c.astype(np.float64) ** 2).sum(1)
+    assert oracle.check_close(cn.cpu().numpy(), ref, rel=1e-6) <= 1e-6
+
+
+def test_merge_of_index_shards_equals_unsharded():
+    x = sift_like(1234, seed=51)
+    c = sift_like(5000, n_modes=512, seed=52)
+    xd = _dev(x)
+    bounds = [0, 1300, 1301, 3333, 5000]  # ragged shards, one of a single row
+    recs = [ops.assign_top2_rec(xd, _dev(c[lo:hi])) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    gathered = torch.stack(recs).contiguous()
+    mi1, md1, mi2, md2, mmask = ops.top2_merge(gathered, bounds[:-1], 0.8)
+    i1, d1, i2, d2, mask = ops.assign_top2(xd, _dev(c), 0.8)
+    rd, ri = oracle.topk(x, c, 3)
+    for got, rank in ((mi1, 0), (mi2, 1)):
+        must, bad, _ = oracle.check_indices(got.cpu().numpy(), ri, rd, rank)
+        assert bad == 0
+    same = (mi1.cpu() == i1.cpu().long()) & (mi2.cpu() == i2.cpu().long())
+    assert same.float().mean() > 0.999
+    assert torch.equal(md1.cpu()[same], d1.cpu()[same])
+
+
+def test_errors_are_loud():
+    x = _dev(np.zeros((4, 128)))
+    with pytest.raises(ValueError):
+        ops.assign_top1(x, _dev(np.zeros((3, 64))))
+    with pytest.raises(RuntimeError):
+        ops.assign_top1(_dev(np.zeros((4, 200))), _dev(np.zeros((3, 200))))
+    with pytest.raises(ValueError):
+        ops.assign_top1(x.cpu(), x)
