@@ -32,6 +32,8 @@ _SIGNATURES = {
     "ic_create": [_c_int, ctypes.POINTER(_p)],
     "ic_destroy": [_p],
     "ic_last_error": [_p],
+    "ic_profile_begin": [_p],
+    "ic_profile_end": [_p, ctypes.POINTER(_c_d), ctypes.POINTER(_c_i64)],
     "ic_row_sqnorm": [_p, _p, _c_i64, _c_int, _p, _p],
     "ic_assign_top1": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
     "ic_assign_top2": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _c_f, _p, _p],

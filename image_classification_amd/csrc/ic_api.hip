@@ -6,6 +6,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "ic_internal.h"
 
@@ -39,6 +41,10 @@ struct Ctx {
   hipEvent_t done = nullptr;      // recorded after each call's last launch
   hipStream_t last_stream = nullptr;
   bool have_last = false;
+  // optional timing of the distance kernel (ic_profile_begin / ic_profile_end)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
 };
 
 Ctx* as_ctx(void* h) {
@@ -158,7 +164,21 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     cs = cp;
   }
   IC_HIP(ic::launch_codebook_norms(cs, k, kpad, c_sqnorm, cn, s), "codebook norms");
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ctx->profiling) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+      hipEvent_t a, b;
+      IC_HIP(hipEventCreate(&a), "hipEventCreate");
+      IC_HIP(hipEventCreate(&b), "hipEventCreate");
+      ctx->ev_pool.emplace_back(a, b);
+    }
+    ev0 = ctx->ev_pool[ctx->ev_used].first;
+    ev1 = ctx->ev_pool[ctx->ev_used].second;
+    ctx->ev_used++;
+    IC_HIP(hipEventRecord(ev0, s), "hipEventRecord");
+  }
   IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, nsplit, part, s), "distance/top-2 kernel");
+  if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   IC_HIP(ic::launch_rescore(xs, n, cs, part, nsplit, i1, d1, i2, d2, ratio, mask, rec, s),
          "rescore kernel");
   return finish_call(ctx, s);
@@ -208,11 +228,45 @@ int ic_destroy(void* handle) {
       (void)hipDeviceSynchronize();
       if (c->ws) (void)hipFree(c->ws);
       if (c->done) (void)hipEventDestroy(c->done);
+      for (auto& pr : c->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+      }
     }
     c->ws = nullptr;
     c->magic = 0;
   }
   delete c;
+  return IC_OK;
+}
+
+int ic_profile_begin(void* handle) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_profile_begin: invalid handle");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->profiling = true;
+  ctx->ev_used = 0;
+  return IC_OK;
+}
+
+int ic_profile_end(void* handle, double* kernel_ms_sum, int64_t* launches) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_profile_end: invalid handle");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  double sum = 0.0;
+  for (size_t i = 0; i < ctx->ev_used; ++i) {
+    IC_HIP(hipEventSynchronize(ctx->ev_pool[i].second), "hipEventSynchronize");
+    float ms = 0.f;
+    IC_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second),
+           "hipEventElapsedTime");
+    sum += ms;
+  }
+  if (kernel_ms_sum) *kernel_ms_sum = sum;
+  if (launches) *launches = (int64_t)ctx->ev_used;
+  ctx->profiling = false;
+  ctx->ev_used = 0;
   return IC_OK;
 }
 

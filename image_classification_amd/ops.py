@@ -176,3 +176,17 @@ def centroid_finalize(sums, counts, prev_c):
                                           _ptr(new_c), _ptr(has), _stream_ptr(dev))
     _lib.check(rc, "ic_centroid_finalize")
     return new_c, has
+
+
+def profile_begin(device_index):
+    """Start timing the distance kernel of every following assign call on this device."""
+    _lib.check(_lib.load().ic_profile_begin(_lib.handle(device_index)), "ic_profile_begin")
+
+
+def profile_end(device_index):
+    """(summed kernel milliseconds, launches) since profile_begin; waits for the kernels."""
+    ms = ctypes.c_double(0.0)
+    n = ctypes.c_int64(0)
+    rc = _lib.load().ic_profile_end(_lib.handle(device_index), ctypes.byref(ms), ctypes.byref(n))
+    _lib.check(rc, "ic_profile_end")
+    return ms.value, n.value

@@ -53,6 +53,13 @@ int ic_create(int device, void** handle);
 int ic_destroy(void* handle);
 const char* ic_last_error(void* handle); /* handle may be NULL: error of the last failed ic_create */
 
+/* Timing of the distance kernel with HIP events recorded on the caller's stream, one pair per
+ * ic_assign_* call between begin and end.  ic_profile_end waits for those events and returns
+ * the summed kernel time in milliseconds and the number of launches.  No counterpart in the
+ * reference; used by bench.py for the roofline figure. */
+int ic_profile_begin(void* handle);
+int ic_profile_end(void* handle, double* kernel_ms_sum, int64_t* launches);
+
 /* out[i] = sum_j x[i][j]^2.  Replaces the squared-norm terms scipy's _vq.vq and sklearn's
  * euclidean_distances compute implicitly (model/features.py:1166,
  * vision/utils/scene_functions.py:391). */
