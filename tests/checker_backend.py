@@ -1,0 +1,106 @@
+"""A backend for the host-logic tests on machines without a GPU (TEST INFRASTRUCTURE).
+
+It implements the interface of image_classification_amd.backend.HipBackend with the float64 CPU
+oracle and torch CPU tensors, so that batching, sharding, the Lloyd loop and the collectives can be
+exercised by `pytest -m "not gpu"` and by the gloo multi-process tests.  It lives under tests/ on
+purpose: the package never imports it and has no CPU path of its own.
+"""
+import numpy as np
+import torch
+
+import oracle
+
+
+class _Codebook(object):
+    def __init__(self, c):
+        self.c = c
+        self.sqnorm = (c.double() ** 2).sum(1).float()
+        self.device = c.device
+
+    @property
+    def shape(self):
+        return tuple(self.c.shape)
+
+
+class CheckerBackend(object):
+    name = "cpu-oracle-checker"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.calls = []
+
+    def f32(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+    def i32(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.int32)
+
+    def i64(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.int64)
+
+    def codebook(self, c):
+        if isinstance(c, _Codebook):
+            return c
+        return _Codebook(self.f32(np.asarray(c)))
+
+    def make_codebook(self, c_dev):
+        return _Codebook(c_dev)
+
+    def _top(self, x, cb, kk):
+        self.calls.append(("search", tuple(x.shape), cb.shape))
+        return oracle.topk(x.numpy(), cb.c.numpy(), kk)
+
+    def assign_top1(self, x, cb, want_dist=True):
+        d, i = self._top(x, cb, 1)
+        idx = torch.from_numpy(i[:, 0].astype(np.int32))
+        return idx, (torch.from_numpy(d[:, 0].astype(np.float32)) if want_dist else None)
+
+    def assign_top2(self, x, cb, ratio=0.8):
+        d, i = self._top(x, cb, 2)
+        d32 = d.astype(np.float32)
+        mask = (d32[:, 0] < d32[:, 1] * np.float32(ratio)).astype(np.uint8)
+        return (torch.from_numpy(i[:, 0].astype(np.int32)), torch.from_numpy(d32[:, 0].copy()),
+                torch.from_numpy(i[:, 1].astype(np.int32)), torch.from_numpy(d32[:, 1].copy()),
+                torch.from_numpy(mask))
+
+    def assign_top2_rec(self, x, cb):
+        d, i = self._top(x, cb, 2)
+        rec = np.empty((x.shape[0], 4), dtype=np.int32)
+        rec[:, 0] = d[:, 0].astype(np.float32).view(np.int32)
+        rec[:, 1] = i[:, 0]
+        rec[:, 2] = d[:, 1].astype(np.float32).view(np.int32)
+        rec[:, 3] = i[:, 1]
+        return torch.from_numpy(rec)
+
+    def top2_merge(self, gathered, shard_base, ratio=0.8):
+        g = gathered.numpy()
+        shards = []
+        for s in range(g.shape[0]):
+            d = np.stack([g[s, :, 0].copy().view(np.float32), g[s, :, 2].copy().view(np.float32)], 1)
+            i = np.stack([g[s, :, 1], g[s, :, 3]], 1).astype(np.int64)
+            shards.append((d.astype(np.float64), i))
+        d, i = oracle.top2_merge(shards, list(shard_base))
+        d32 = d.astype(np.float32)
+        mask = (d32[:, 0] < d32[:, 1] * np.float32(ratio)).astype(np.uint8)
+        return (torch.from_numpy(i[:, 0].copy()), torch.from_numpy(d32[:, 0].copy()),
+                torch.from_numpy(i[:, 1].copy()), torch.from_numpy(d32[:, 1].copy()),
+                torch.from_numpy(mask))
+
+    def hist(self, codes, offsets, k, norm="l1", power=0.5):
+        self.calls.append(("hist", int(codes.shape[0]), int(offsets.shape[0]) - 1))
+        c = codes.numpy()
+        off = offsets.numpy()
+        per = [c[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        return torch.from_numpy(oracle.build_histogram(per, int(k), norm, power).reshape(len(per), int(k)))
+
+    def centroid_partials(self, x, codes, k):
+        _, _, sums, counts = oracle.update_cluster_means(x.numpy(), codes.numpy().astype(np.int64), int(k))
+        return torch.from_numpy(sums), torch.from_numpy(counts.astype(np.int64))
+
+    def centroid_finalize(self, sums, counts, prev_c):
+        has = counts > 0
+        new = prev_c.clone()
+        new[has] = (sums[has] / counts[has][:, None].double()).float()
+        return new, has.to(torch.uint8)

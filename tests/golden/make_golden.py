@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the libraries the reference calls on this path.
+
+The reference ships no fixtures, and its arithmetic lives in scipy / scikit-learn / numpy, so the
+golden vectors are those libraries' outputs for the reference's argument patterns:
+
+  g1_vq          scipy.cluster.vq.vq(desc f32, vocab f64)      model/features.py:1166
+  g2_ties        the same on integer data with duplicated codewords (lowest index wins)
+  g3_hist        np.histogram(code, bins=range(0, K+1))[0] * (1.0 / (sum or 1))
+                                                               model/features.py:1174-1181
+  g4_knn         KNeighborsClassifier(2, weights='distance', algorithm='brute').kneighbors(x, 2)
+                 and the ratio test                            model/robust_matching.py:73-84
+  g5_kmeans      scipy.cluster.vq.kmeans2(..., minit='matrix' / 'points')
+                                                               vision/facerec/face_indexing.py:158
+  g6_cvf         argmin(sklearn euclidean_distances(squared=True)) in vocab-sized batches
+                                                               vision/utils/scene_functions.py:385-392
+
+Run from the repository root:  python tests/golden/make_golden.py
+Versions used for the committed files: scipy 1.15.3, scikit-learn 1.7.2, numpy 2.2.6.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy
+import sklearn
+from scipy.cluster.vq import kmeans2, vq
+from sklearn.metrics.pairwise import euclidean_distances
+from sklearn.neighbors import KNeighborsClassifier
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from image_classification_amd.synthetic import sift_like  # noqa: E402
+
+VERSIONS = np.array([scipy.__version__, sklearn.__version__, np.__version__])
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, versions=VERSIONS, **arrays)
+    print("%-12s %7.1f KiB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def g1_vq():
+    x = sift_like(1024, seed=20240601)
+    c32 = sift_like(64, seed=20240602)
+    c64 = c32.astype(np.float64) + np.random.default_rng(20240603).uniform(-1e-3, 1e-3, c32.shape)
+    code64, dist64 = vq(x, c64)          # reference dtypes: float32 descriptors, float64 vocabulary
+    code32, dist32 = vq(x, c32)
+    save("g1_vq", x=x, c64=c64, c32=c32, code64=code64, dist64=dist64, code32=code32, dist32=dist32)
+
+
+def g2_ties():
+    x = sift_like(512, seed=20240604, rounded=True)
+    c = sift_like(48, seed=20240605, rounded=True)
+    c = np.concatenate([c, c[:16], c[5:9]]).astype(np.float64)  # duplicated codewords
+    x[:24] = c[:24]                                              # descriptors equal to codewords
+    code, dist = vq(x, c)
+    save("g2_ties", x=x, c=c, code=code, dist=dist)
+
+
+def g3_hist():
+    rng = np.random.default_rng(20240606)
+    k = 50
+    sizes = [120, 0, 1, 300, 77, 5, 64]  # image 1 is empty; image 5 stands for descriptors=None
+    codes = [rng.integers(0, k, size=s).astype(np.int32) for s in sizes]
+    codes[3][:200] = 7                   # one dominant bin
+    hists = []
+    for code in codes:
+        hist = np.histogram(code, bins=range(0, k + 1))[0]
+        s = hist.sum()
+        hists.append(hist * (1.00 / (s or 1)))
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    save("g3_hist", codes=np.concatenate(codes), offsets=offsets, k=np.int64(k),
+         hists=np.asarray(hists))
+
+
+def g4_knn():
+    rng = np.random.default_rng(20240607)
+    query = sift_like(300, seed=20240608)
+    cand = sift_like(1000, seed=20240609)
+    planted = rng.choice(1000, size=60, replace=False)
+    src = rng.integers(0, 300, size=60)
+    cand[planted] = query[src] + rng.normal(0, 2.0, size=(60, 128)).astype(np.float32)
+    # reference direction: index fitted on the QUERY descriptors, candidate rows searched
+    nbrs = KNeighborsClassifier(n_neighbors=2, weights="distance", algorithm="brute")
+    nbrs.fit(query, range(len(query)))
+    dist, ind = nbrs.kneighbors(cand, n_neighbors=2, return_distance=True)
+    mask = dist[:, 0] < dist[:, 1] * 0.8
+    # transposed direction: index on the candidates, query rows searched
+    nbrs_t = KNeighborsClassifier(n_neighbors=2, weights="distance", algorithm="brute")
+    nbrs_t.fit(cand, range(len(cand)))
+    dist_t, ind_t = nbrs_t.kneighbors(query, n_neighbors=2, return_distance=True)
+    save("g4_knn", query=query, cand=cand, dist=dist, ind=ind, mask=mask, dist_t=dist_t,
+         ind_t=ind_t, planted=planted, src=src)
+
+
+def g5_kmeans():
+    data = sift_like(1536, n_modes=24, seed=20240610).astype(np.float64)
+    rng = np.random.default_rng(20240611)
+    init = data[rng.choice(len(data), size=32, replace=False)].copy()
+    cb, label = kmeans2(data, init, iter=5, minit="matrix")
+    cb1, label1 = kmeans2(data, init, iter=1, minit="matrix")
+    # forced empty cluster: one initial centroid far from all data keeps its position
+    init_e = init.copy()
+    init_e[3] = 1e4
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        cb_e, label_e = kmeans2(data, init_e, iter=3, minit="matrix")
+    assert any("empty" in str(x.message) for x in w)
+    # minit='points' with a seeded generator (the reference's call, face_indexing.py:158)
+    cb_p, label_p = kmeans2(data, 16, iter=5, minit="points", rng=np.random.default_rng(20240612))
+    save("g5_kmeans", data=data.astype(np.float32), init=init, cb=cb, label=label, cb1=cb1,
+         label1=label1, init_e=init_e, cb_e=cb_e, label_e=label_e, cb_p=cb_p, label_p=label_p,
+         seed_p=np.int64(20240612))
+
+
+def g6_cvf():
+    vocab = sift_like(48, seed=20240613)
+    feat = sift_like(1000, seed=20240614)  # 1000 is not a multiple of 48: ragged last batch
+    batch = vocab.shape[0]
+    codes = np.zeros(feat.shape[0], dtype=np.int64)
+    for i in range(0, feat.shape[0], batch):
+        sl = slice(i, i + batch)
+        codes[sl] = np.argmin(euclidean_distances(feat[sl, :], vocab, squared=True), axis=1)
+    save("g6_cvf", vocab=vocab, feat=feat, codes=codes)
+
+
+if __name__ == "__main__":
+    g1_vq()
+    g2_ties()
+    g3_hist()
+    g4_knn()
+    g5_kmeans()
+    g6_cvf()

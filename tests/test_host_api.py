@@ -1,0 +1,298 @@
+"""The reference-shaped Python API against the golden vectors.
+
+Every test takes the `backend` fixture: it runs on the CPU checker backend under
+`-m "not gpu"` (host logic only) and on the shipped HIP backend under `-m gpu` (the product).
+Tolerances: indices equal wherever the oracle's gap to the next candidate exceeds 1e-5 relative,
+distances / centroids / histograms within 1e-4 relative (L1 histograms: bit-exact).
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle
+from image_classification_amd import (BagOfWords, ImageDesc, KNNScikit, RobustMatcher, Vocabulary,
+                                      compute_vocab_features, kmeans2, kmeans_assign, vq)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL = 1e-4
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+# ---- vq ------------------------------------------------------------------------------------------
+def test_vq_reference_dtypes(backend):
+    g = load("g1_vq")
+    code, dist = vq(g["x"], g["c64"], backend=backend)
+    assert code.dtype == np.int32 and dist.dtype == np.float64 and code.shape == (1024,)
+    rd, ri = oracle.topk(g["x"], g["c64"], 2)
+    must, bad, agree = oracle.check_indices(code, ri, rd, 0)
+    assert bad == 0 and agree >= 0.999
+    same = code == g["code64"]
+    assert oracle.check_close(dist[same], g["dist64"][same]) <= REL
+    code32, dist32 = vq(g["x"], g["c32"], backend=backend)
+    assert dist32.dtype == np.float32
+
+
+def test_vq_ties_and_zero_distance(backend):
+    g = load("g2_ties")
+    code, dist = vq(g["x"], g["c"], backend=backend)
+    assert np.array_equal(code, g["code"])
+    assert np.all(dist[:24] == 0)
+    assert oracle.check_close(dist, g["dist"]) <= REL
+
+
+def test_vq_argument_errors(backend):
+    x = np.zeros((4, 8), dtype=np.float32)
+    with pytest.raises(ValueError):
+        vq(x, np.zeros((3, 7)), backend=backend)
+    with pytest.raises(ValueError):
+        vq(x, np.zeros(8), backend=backend)
+    bad = x.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(ValueError):
+        vq(bad, np.zeros((3, 8)), backend=backend)
+    code, dist = vq(np.zeros((0, 8), dtype=np.float32), np.zeros((3, 8)), backend=backend)
+    assert code.shape == (0,) and dist.shape == (0,)
+    # 1-D observations and code book, as scipy accepts
+    code, dist = vq(np.array([0.1, 2.2, 0.9]), np.array([0.0, 1.0, 2.0]), backend=backend)
+    assert list(code) == [0, 2, 1]
+
+
+def test_kmeans_assign_and_compute_vocab_features(backend):
+    g = load("g6_cvf")
+    codes = compute_vocab_features(g["vocab"], g["feat"], backend=backend)
+    assert codes.dtype == np.int64 and codes.shape == (1000,)
+    rd, ri = oracle.topk(g["feat"], g["vocab"], 2)
+    must, bad, agree = oracle.check_indices(codes, ri, rd, 0)
+    assert bad == 0 and agree >= 0.999
+    idx = kmeans_assign(g["feat"], g["vocab"], backend=backend)
+    assert idx.dtype == np.int32 and np.array_equal(idx, codes)
+    with pytest.raises(ValueError):
+        compute_vocab_features(g["vocab"], g["feat"][:, :64], backend=backend)
+    assert compute_vocab_features(g["vocab"], g["feat"][:0], backend=backend).shape == (0,)
+
+
+# ---- BagOfWords ------------------------------------------------------------------------------------
+class FakeExtractor(object):
+    """Stands in for the cv2 SURF extractor: returns (keypoints, descriptors) per image."""
+
+    def __init__(self, per_image):
+        self.per_image = per_image
+
+    def extract(self, image_list):
+        return [self.per_image[i] for i in image_list]
+
+
+def _images_from_codes(vocab, codes_per_image, rng):
+    """Descriptors that quantise to given codes: codeword + small noise."""
+    out = []
+    for codes in codes_per_image:
+        if codes is None:
+            out.append(([], None))
+            continue
+        desc = (vocab[codes] + rng.normal(0, 0.5, size=(len(codes), vocab.shape[1]))).astype(np.float32)
+        out.append(([(float(i), float(2 * i)) for i in range(len(codes))], desc))
+    return out
+
+
+def test_bag_of_words_extract_matches_reference_rule(backend):
+    g = load("g3_hist")
+    k = int(g["k"])
+    rng = np.random.default_rng(5)
+    from image_classification_amd.synthetic import sift_like
+    vocab = sift_like(k, seed=77).astype(np.float64)
+    off = g["offsets"]
+    codes = [g["codes"][off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    codes[5] = None  # an image whose extractor found nothing
+    per_image = _images_from_codes(vocab, codes, rng)
+    bow = BagOfWords(FakeExtractor(per_image), vocab=vocab, backend=backend)
+    descs, hists = bow.extract(list(range(len(per_image))))
+    assert len(descs) == 7 and isinstance(descs[0], ImageDesc)
+    assert hists.shape == (7, k) and hists.dtype == np.float64
+    expect = g["hists"].copy()
+    expect[5] = 0
+    assert np.array_equal(hists, expect)            # L1: bit-exact
+    assert descs[5].descriptors is None and descs[5].desc_rows == 0
+    # one search and one histogram call for the whole batch, not one per image
+    if hasattr(backend, "calls"):
+        assert [c[0] for c in backend.calls] == ["search", "hist"]
+    # extension modes against the build's own restatement
+    for norm in ("l2", "power_l2", "none"):
+        bow_n = BagOfWords(FakeExtractor(per_image), vocab=vocab, norm=norm, backend=backend)
+        _, h = bow_n.extract(list(range(len(per_image))))
+        codes_l = [c if c is not None else [] for c in codes]
+        assert oracle.check_close(h, oracle.build_histogram(codes_l, k, norm), rel=1e-12) <= 1e-12
+
+
+def test_bag_of_words_subclass_histogram_override_and_empty_inputs(backend):
+    from image_classification_amd.synthetic import sift_like
+    vocab = sift_like(16, seed=78).astype(np.float64)
+    rng = np.random.default_rng(6)
+    per_image = _images_from_codes(vocab, [np.array([1, 1, 3]), None, np.array([15])], rng)
+    seen = {}
+
+    class MyBow(BagOfWords):
+        def _build_histogram(self, image_descs, codebooks):
+            seen["codebooks"] = codebooks
+            return "custom"
+
+    bow = MyBow(FakeExtractor(per_image), vocab=vocab, backend=backend)
+    _, h = bow.extract([0, 1, 2])
+    assert h == "custom"
+    assert list(seen["codebooks"][0]) == [1, 1, 3] and list(seen["codebooks"][1]) == []
+    assert list(seen["codebooks"][2]) == [15]
+    plain = BagOfWords(FakeExtractor(per_image), vocab=vocab, backend=backend)
+    _, h = plain.extract([1])          # only an image without descriptors
+    assert h.shape == (1, 16) and np.all(h == 0)
+    direct = plain._build_histogram(None, [[0, 0, 5], [], np.array([2])])
+    assert np.array_equal(direct, oracle.build_histogram([[0, 0, 5], [], [2]], 16))
+    with pytest.raises(AssertionError):
+        BagOfWords(FakeExtractor(per_image), backend=backend)      # neither vocab nor vocabsize
+    with pytest.raises(AssertionError):
+        ImageDesc([(0, 0)], np.zeros((2, 4)))                      # keypoints != descriptor rows
+
+
+def test_bag_of_words_train_learns_vocabulary(backend, tmp_path):
+    from image_classification_amd.synthetic import sift_like
+    rng = np.random.default_rng(8)
+    per_image = []
+    for i in range(6):
+        d = sift_like(80, n_modes=8, seed=300 + i)
+        per_image.append(([(0.0, 0.0)] * 80, d))
+    bow = BagOfWords(FakeExtractor(per_image), vocabsize=8, backend=backend)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        descs, hists = bow.train(list(range(6)))
+    assert bow.vocab.shape == (8, 128) and bow.vocab.dtype == np.float64
+    assert hists.shape == (6, 8)
+    np.testing.assert_allclose(hists.sum(1), 1.0, rtol=1e-12)
+    v = Vocabulary(200, backend=backend)
+    with pytest.raises(AssertionError):
+        v.train(per_image[0][1])       # more clusters than descriptors
+    path = str(tmp_path / "vocab.npy")
+    bow._vocab_trainer.save_to_file(path)
+    assert np.array_equal(Vocabulary.load_from_file(path).vocab, bow.vocab)
+
+
+# ---- k-NN / robust matching -----------------------------------------------------------------------
+def test_knn_scikit_get_neighbors(backend):
+    g = load("g4_knn")
+    knn = KNNScikit(2, weights="distance", algorithm="brute", backend=backend)
+    knn.train(g["query"], range(300))
+    knn.train(g["cand"], range(1000))   # ignored: already trained (model/classifiers.py:175)
+    dist, ind = knn.get_neighbors(g["cand"], 2)
+    assert dist.dtype == np.float64 and ind.dtype == np.int64 and ind.shape == (1000, 2)
+    rd, ri = oracle.topk(g["cand"], g["query"], 3)
+    for rank in (0, 1):
+        must, bad, agree = oracle.check_indices(ind[:, rank], ri, rd, rank)
+        assert bad == 0 and agree >= 0.995
+    same = np.all(ind == g["ind"], axis=1)
+    assert same.mean() >= 0.995
+    assert oracle.check_close(dist[same], g["dist"][same]) <= REL
+    only = knn.get_neighbors(g["cand"], 2, dist=False)
+    assert np.array_equal(only, ind)
+    d1, i1 = knn.get_neighbors(g["cand"][:10], 1)
+    assert i1.shape == (10, 1) and np.array_equal(i1[:, 0], ind[:10, 0])
+    with pytest.raises(NotImplementedError):
+        knn.get_neighbors(g["cand"], 3)
+    with pytest.raises(ValueError):
+        knn.get_neighbors(g["cand"], 301)
+    with pytest.raises(ValueError):
+        knn.get_neighbors(g["cand"][:, :64], 2)
+    with pytest.raises(NotImplementedError):
+        KNNScikit(2, metric="manhattan", backend=backend)
+    with pytest.raises(RuntimeError):
+        KNNScikit(2, backend=backend).get_neighbors(g["cand"], 2)
+
+
+def _desc(d):
+    n = 0 if d is None else len(d)
+    return ImageDesc([(float(i), float(i % 7)) for i in range(n)], d)
+
+
+def test_robust_matcher_descriptor_stage(backend):
+    g = load("g4_knn")
+    query = _desc(g["query"])
+    cands = [g["cand"][:400], g["cand"][400:405], None, g["cand"][405:]]
+    images = [_desc(c) for c in cands]
+    rm = RobustMatcher(min_points=5, min_matches=4, knn_thresh=0.8, backend=backend,
+                       homography_fn=lambda q, im: (None, np.ones(len(q), dtype=np.uint8)))
+    got = rm.match_descriptors(query, images)
+    ref = oracle.robust_match_descriptors(g["query"], cands, 5, 0.8)
+    # rows whose ratio sits within 1e-5 of the threshold may fall either way
+    dist, _ = oracle.kneighbors(g["query"], g["cand"], 2)
+    edge = np.abs(dist[:, 0] - 0.8 * dist[:, 1]) / dist[:, 1] < 1e-5
+    assert not edge.any()
+    for (gq, gi), (rq, ri) in zip(got, ref):
+        assert np.array_equal(gi, ri) and np.array_equal(gq, rq)
+    scores = rm.match(query, images)
+    assert len(scores) == 4 and scores[1] == 0 and scores[2] == 0
+    assert scores[0] == 1.0 and scores[3] == 1.0     # the stub declares every match an inlier
+    assert rm.predict(scores, ["a", "b", "c", "d"]) == "a"
+    assert rm.predict([0.1, 0.2], ["a", "b"]) == -1
+    assert rm.predict([1.5, 0.4], ["a", "b"]) == "b"  # scores above 1 are zeroed
+    # query with too few points: all zeros, nothing searched
+    few = RobustMatcher(min_points=500, min_matches=4, backend=backend)
+    assert few.match(query, images) == [0, 0, 0, 0]
+    # candidates that yield <= min_matches matches are not sent to the homography stage
+    strict = RobustMatcher(min_points=5, min_matches=10 ** 6, backend=backend)
+    assert strict.match(query, images) == [0.0, 0.0, 0.0, 0.0]
+    with pytest.raises(AssertionError):
+        rm.predict([0.1], ["a", "b"])
+
+
+# ---- kmeans2 -------------------------------------------------------------------------------------
+def _cb_err(got, ref):
+    return float(np.max(np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)))
+
+
+def test_kmeans2_matrix_init(backend):
+    g = load("g5_kmeans")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cb, label = kmeans2(g["data"], g["init"], iter=5, minit="matrix", backend=backend)
+    assert cb.shape == (32, 128) and label.dtype == np.int32
+    assert np.mean(label == g["label"]) >= 0.999
+    assert _cb_err(cb, g["cb"]) <= REL
+    cb1, _ = kmeans2(g["data"], g["init"], iter=1, minit="matrix", backend=backend)
+    assert _cb_err(cb1, g["cb1"]) <= REL
+
+
+def test_kmeans2_empty_cluster_keeps_centroid_and_warns(backend):
+    g = load("g5_kmeans")
+    with pytest.warns(UserWarning, match="empty"):
+        cb, label = kmeans2(g["data"], g["init_e"], iter=3, minit="matrix", backend=backend)
+    assert np.all(cb[3] == np.float32(1e4))
+    assert np.mean(label == g["label_e"]) >= 0.999
+    assert _cb_err(cb, g["cb_e"]) <= REL
+    with pytest.raises(RuntimeError):
+        kmeans2(g["data"], g["init_e"], iter=3, minit="matrix", missing="raise", backend=backend)
+
+
+def test_kmeans2_points_init_uses_scipy_generator_call(backend):
+    g = load("g5_kmeans")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cb, label = kmeans2(g["data"].astype(np.float64), 16, iter=5, minit="points",
+                            rng=np.random.default_rng(int(g["seed_p"])), backend=backend)
+    assert cb.dtype == np.float64
+    assert np.mean(label == g["label_p"]) >= 0.999
+    assert _cb_err(cb, g["cb_p"]) <= REL
+
+
+def test_kmeans2_argument_errors(backend):
+    x = np.zeros((10, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        kmeans2(x, 3, iter=0, backend=backend)
+    with pytest.raises(ValueError):
+        kmeans2(x, 3, minit="random", backend=backend)
+    with pytest.raises(ValueError):
+        kmeans2(x, np.zeros((2, 5)), minit="matrix", backend=backend)
+    with pytest.raises(ValueError):
+        kmeans2(x, 11, minit="points", backend=backend)
+    with pytest.raises(ValueError):
+        kmeans2(x, 3, missing="ignore", backend=backend)
