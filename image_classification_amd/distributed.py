@@ -1,0 +1,155 @@
+"""Multi-GPU decomposition of the path: one process per GPU, torch.distributed (backend "nccl" is
+RCCL on ROCm) for the two steps that really exchange data.
+
+  * assignment / BoW quantisation / video batches: rows are independent, so each rank takes a
+    contiguous block of images and there is NO collective (`quantize_sharded`; the optional gather
+    of the histograms to one rank is for the caller's convenience only).
+  * k-means training: rows sharded, one all-reduce(sum) per Lloyd iteration over a single packed
+    float64 buffer holding the centroid sums and the member counts (`kmeans_fit_sharded`).
+  * 2-NN with the INDEX side sharded (the logo database of model/robust_matching.py split over
+    GPUs): every rank searches the replicated queries in its shard, the 16-byte per-row records
+    are all-gathered and merged by (distance, global index) (`knn2_index_sharded`).
+  * 2-NN with the SEARCH rows sharded (the reference's own direction, model/robust_matching.py:80:
+    the index is fitted on the query image): rows are independent, results concatenate
+    (`knn2_rows_sharded`).
+
+The reference has no distributed code; these functions have no counterpart there.  Every function
+takes the compute backend explicitly (HipBackend by default), so the collectives and the sharding
+arithmetic are testable with gloo on CPU-only machines.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .backend import default_backend
+from .clustering import lloyd
+
+
+def world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_bounds(n_items, n_shards):
+    """Contiguous blocks, sizes differing by at most one: int64 [n_shards + 1]."""
+    base, rem = divmod(int(n_items), int(n_shards))
+    sizes = [base + (1 if r < rem else 0) for r in range(n_shards)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def shard_images(offsets, n_shards):
+    """Split images (not rows) into contiguous blocks of nearly equal row counts.
+
+    offsets: int64 [n_img + 1].  Returns image bounds int64 [n_shards + 1]; shard r owns images
+    [b[r], b[r+1]) and therefore rows [offsets[b[r]], offsets[b[r+1]]).
+    """
+    offsets = np.asarray(offsets, dtype=np.int64)
+    total = offsets[-1]
+    targets = [total * r // n_shards for r in range(1, n_shards)]
+    cuts = [int(np.searchsorted(offsets, t, side="left")) for t in targets]
+    b = np.asarray([0] + cuts + [len(offsets) - 1], dtype=np.int64)
+    return np.maximum.accumulate(b)
+
+
+def quantize_sharded(x_local, offsets_local, codebook, norm="l1", power=0.5, backend=None,
+                     gather_to=None, group=None):
+    """BoW quantisation of this rank's images.  Returns (codes, hists) for the local images; with
+    `gather_to=r` rank r also receives the list of every rank's histograms (others get None)."""
+    b = backend or default_backend()
+    cb = b.codebook(codebook)
+    xd = b.f32(x_local)
+    off = b.i64(offsets_local)
+    if xd.shape[0]:
+        codes, _ = b.assign_top1(xd, cb, want_dist=False)
+    else:
+        codes = b.i32(np.empty(0, dtype=np.int32))
+    hists = b.hist(codes, off, cb.shape[0], norm, power)
+    gathered = None
+    rank, n = world(group)
+    if gather_to is not None and n > 1:
+        gathered = gather_rows(hists, group=group)
+        if rank != gather_to:
+            gathered = None
+    elif gather_to is not None:
+        gathered = [hists]
+    return codes, hists, gathered
+
+
+def gather_rows(t, group=None):
+    """All-gather tensors whose first dimension differs per rank; returns the list of them."""
+    rank, n = world(group)
+    if n == 1:
+        return [t]
+    sizes = torch.zeros(n, dtype=torch.int64, device=t.device)
+    sizes[rank] = t.shape[0]
+    dist.all_reduce(sizes, group=group)
+    sizes = [int(s) for s in sizes.cpu()]
+    m = max(sizes)
+    padded = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    padded[:t.shape[0]] = t
+    out = [torch.empty_like(padded) for _ in range(n)]
+    dist.all_gather(out, padded, group=group)
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
+def make_allreduce(group=None):
+    """In-place sum over ranks of (sums float64 [k,d], counts int64 [k]) as ONE packed buffer."""
+    def allreduce(sums, counts):
+        k, d = sums.shape
+        buf = torch.empty(k * d + k, dtype=torch.float64, device=sums.device)
+        buf[:k * d] = sums.reshape(-1)
+        buf[k * d:] = counts.to(torch.float64)      # exact below 2^53 members
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        sums.copy_(buf[:k * d].reshape(k, d))
+        counts.copy_(buf[k * d:].round().to(torch.int64))
+    return allreduce
+
+
+def kmeans_fit_sharded(x_local, init, iters, backend=None, group=None, on_empty=None):
+    """Lloyd iterations with the rows sharded over ranks.
+
+    x_local: this rank's rows; init: [k, d] initial centroids, identical on every rank (broadcast
+    from rank 0 here to make sure).  Returns (codebook device tensor, identical on all ranks;
+    labels of the local rows; empty-cluster count per iteration).
+    """
+    b = backend or default_backend()
+    rank, n = world(group)
+    xd = b.f32(x_local)
+    c0 = b.f32(init)
+    if n > 1:
+        dist.broadcast(c0, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                       group=group)
+    return lloyd(xd, c0, iters, b, allreduce=make_allreduce(group) if n > 1 else None,
+                 on_empty=on_empty)
+
+
+def knn2_index_sharded(queries, index_local, index_base, ratio=0.8, backend=None, group=None):
+    """Two nearest index rows of every query when the index is split over ranks.
+
+    queries: replicated [n, d]; index_local: this rank's index rows; index_base: global row number
+    of its first row.  Returns (i1 int64, d1, i2 int64, d2, mask) identical on every rank.
+    """
+    b = backend or default_backend()
+    rank, n = world(group)
+    rec = b.assign_top2_rec(b.f32(queries), b.codebook(index_local))
+    if n == 1:
+        return b.top2_merge(rec.unsqueeze(0).contiguous(), [int(index_base)], ratio)
+    rows = rec.shape[0]
+    flat = torch.empty((n * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)  # rank r -> rows [r*rows, ..)
+    gathered = flat.view(n, rows, rec.shape[1])
+    bases = torch.zeros(n, dtype=torch.int64, device=rec.device)
+    bases[rank] = int(index_base)
+    dist.all_reduce(bases, group=group)
+    return b.top2_merge(gathered, [int(v) for v in bases.cpu()], ratio)
+
+
+def knn2_rows_sharded(index, rows_local, ratio=0.8, backend=None, gather=False, group=None):
+    """The reference's direction: the (small) index is replicated, the search rows are sharded.
+    Rows are independent; `gather=True` concatenates every rank's results on every rank."""
+    b = backend or default_backend()
+    res = b.assign_top2(b.f32(rows_local), b.codebook(index), ratio)
+    if not gather:
+        return res
+    return tuple(torch.cat(gather_rows(t, group=group)) for t in res)
