@@ -21,6 +21,8 @@
 //     load is lane-linear) so that ds_read_b128 is bank-conflict free with immediate offsets.
 //   * grid = row tiles x K-splits; every workgroup writes one (value, index) x 2 record per row,
 //     k_rescore merges the splits.
+#include <cstdlib>
+
 #include "ic_internal.h"
 
 namespace ic {
@@ -37,8 +39,10 @@ constexpr int kStageBytes = kStageTileBytes + kStageK * 4;  // + 64 squared norm
 static_assert(kStageTileBytes % 1024 == 0, "a stage must be a whole number of 1 KiB pieces");
 static_assert(kStageBytes % 16 == 0, "stage buffers must stay 16-byte aligned");
 
-// Geometry of the shipped instantiation: 8 waves (two per SIMD, so one wave's top-2 update runs
-// beside the other's MFMAs), each holding 2 x 32 descriptors.
+// Geometry of the shipped instantiation: 8 waves (two per SIMD: LDS-read latency, barriers and the
+// 18 wait states between an MFMA and a vector read of its result are covered by the partner
+// wave), each holding 2 x 32 descriptors; 206 VGPRs, no spills.  Four waves holding 4 x 32
+// descriptors each (one wave per SIMD) made hipcc spill 170+ registers and was dropped.
 constexpr int kXT = 2;
 constexpr int kNW = 8;
 constexpr int kRowsPerWg = kXT * kNW * 32;  // 512
@@ -191,6 +195,41 @@ __device__ __forceinline__ void compute_tile(const char* tile_base, const char* 
   }
 }
 
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+  return __builtin_fminf(__builtin_fminf(a, b), c);
+}
+
+// Ranking with an early out.  On gfx950 the f32 MFMA runs at the vector-ALU rate, and ranking
+// instructions hand-placed between the MFMAs of a chain did not hide behind them (measured: the
+// interleaved schedule was 6 % slower than ranking after the chain, and the same loop without any
+// ranking reaches 94.8 % of the MFMA peak against 83 % with it).  So ranking is made cheaper by
+// doing less of it: the minimum of the tile's 16 values (8 v_min3) is compared with the running
+// second best, and when no lane of the wave can improve its top-2 the update is skipped.
+template <int XT>
+__device__ __forceinline__ void tile_epilogue_skip(const f32x16 (&acc)[XT], Top2 (&st)[XT],
+                                                   int encbase) {
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    const f32x16& a = acc[xt];
+    const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
+                          min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
+                          __builtin_inff());
+    if (__builtin_amdgcn_ballot_w64(m < st[xt].d2) != 0) {
+      // rank inside the tile with the register number (an inline constant) as index; -1 / -2
+      // stand for "the previous best / second best", resolved once after the 16 updates
+      float d1 = st[xt].d1, d2 = st[xt].d2;
+      int l1 = -1, l2 = -2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) top2_update(d1, d2, l1, l2, a[r], r);
+      const int o1 = st[xt].i1, o2 = st[xt].i2;
+      st[xt].d1 = d1;
+      st[xt].d2 = d2;
+      st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
+      st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
+    }
+  }
+}
+
 template <int XT>
 __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st)[XT], int encbase) {
 #pragma unroll
@@ -201,7 +240,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st
   }
 }
 
-template <int XT, int NW>
+template <int XT, int NW, bool SKIP>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ cnp, int stages_total, int stages_per_split, int row_tiles,
@@ -255,14 +294,16 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   for (int st = st0; st < st1; ++st) {
     char* sb = smem + ((st - st0) & 1) * kStageBytes;
     compute_tile<XT>(sb, sb + kStageTileBytes, xr, acc, j, h);
-    tile_epilogue<XT>(acc, best, (st * 2) * 16);
+    if constexpr (SKIP) tile_epilogue_skip<XT>(acc, best, (st * 2) * 16);
+    else tile_epilogue<XT>(acc, best, (st * 2) * 16);
     compute_tile<XT>(sb + kTileK * kRowBytes, sb + kStageTileBytes + kTileK * 4, xr, acc, j, h);
     // every wave is done reading this buffer once it passes the barrier; the stage issued one
     // iteration ago has landed in the other buffer by then
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
-    tile_epilogue<XT>(acc, best, (st * 2 + 1) * 16);
+    if constexpr (SKIP) tile_epilogue_skip<XT>(acc, best, (st * 2 + 1) * 16);
+    else tile_epilogue<XT>(acc, best, (st * 2 + 1) * 16);
   }
 
   // decode (tile, register) -> codeword index, fold the two lane halves, store
@@ -295,7 +336,12 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
   const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
   const int64_t stages = (k + kStageK - 1) / kStageK;
   const int64_t per = (stages + nsplit - 1) / nsplit;
-  auto kern = k_top2_partial<kXT, kNW>;
+  // IC_AMD_VARIANT=0 selects the kernel without the early out (for A/B timing in one build)
+  static const bool no_skip = [] {
+    const char* v = getenv("IC_AMD_VARIANT");
+    return v && atoi(v) == 0;
+  }();
+  auto kern = no_skip ? k_top2_partial<kXT, kNW, false> : k_top2_partial<kXT, kNW, true>;
   const int lds = 2 * kStageBytes;
   // per device and cheap, so it is simply repeated on every call
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
