@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the descriptor -> codeword assignment path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload bow|knn|kmeans|video]
 
-One step = one pass of the hot path over one batch of synthetic descriptors resident in HBM:
-BASELINE config 2, "BoW quantisation + per-image L2-normalised histograms: 1M descriptors x
-10k-word codebook, 128-d" = ic_assign_top1 over [1M,128] x [10k,128] followed by ic_hist (1000
-images x 1000 descriptors, L2).  With N > 1 (launched by torch.distributed.run, one rank per GPU)
-every rank processes its own 1M descriptors -- the path shards by rows and needs no collective --
-so scaling is weak and `value` is the sum over ranks.
+One step = one pass of the hot path over one batch of synthetic descriptors resident in HBM.
+The default workload is BASELINE config 2, "BoW quantisation + per-image L2-normalised histograms:
+1M descriptors x 10k-word codebook, 128-d": ic_assign_top1 over [1M,128] x [10k,128] followed by
+ic_hist (1000 images x 1000 descriptors, L2).  With N > 1 (launched by torch.distributed.run, one
+rank per GPU) every rank processes its own 1M descriptors -- the path shards by rows and needs no
+collective -- so scaling is weak and `value` is the sum over ranks.
+
+The other workloads are the remaining BASELINE configs at their per-GPU size (they are parity /
+sizing cases, run by hand for DESIGN.md, not the line the driver records):
+  knn     config 3: 4k queries vs a 2M-descriptor index split over N ranks, top-2 + ratio test,
+          all-gather + merge of the per-rank records
+  kmeans  config 4: one Lloyd iteration over 10M/8 rows, K = 65536, all-reduce of sums/counts
+  video   config 5: 2000 frames x 2k descriptors per GPU, K = 10k, power-L2 histograms
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA distance /
 top-2 kernel): algorithmic FLOPs per launch = 2 * N * K * D, divided by its average duration
-measured with HIP events recorded on the launch stream inside the timed region.  `cpu_baseline`
+measured with HIP events recorded on the launch stream inside the timed region; `traffic` is that
+kernel's HBM bytes per launch from the newest profiles/*_traffic.json (rocprofv3 --pmc FETCH_SIZE /
+WRITE_SIZE passes of the default workload, read side doubled as gfx950 requires).  `cpu_baseline`
 (rank 0, N == 1 only) times the float64 numpy oracle on a bounded row sample of the same workload.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -27,14 +37,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_ROWS = 1_000_000
-K_WORDS = 10_000
 DIM = 128
-N_IMAGES = 1000
 FP32_MFMA_PEAK_TFLOPS = 157.3  # 256 CU x 256 FLOP/clk x 2.4 GHz
 
+WORKLOADS = {
+    "bow": dict(rows=1_000_000, k=10_000, images=1000, norm="l2",
+                name="BASELINE config 2: BoW quantisation + per-image L2 histograms, 1M descriptors "
+                     "x 10k-word codebook x 128-d per GPU (1000 images x 1000 descriptors)"),
+    "video": dict(rows=4_000_000, k=10_000, images=2000, norm="power_l2",
+                  name="BASELINE config 5 (per-GPU share): 2000 frames x 2000 descriptors, 10k words, "
+                       "assignment + per-frame power/L2 histograms"),
+    "kmeans": dict(rows=1_250_000, k=65_536,
+                   name="BASELINE config 4 (per-GPU share): one Lloyd iteration, 1.25M rows x 65536 "
+                        "centroids x 128-d, all-reduce of sums/counts"),
+    "knn": dict(rows=4000, k=2_000_000,
+                name="BASELINE config 3: 4k query descriptors vs 2M-descriptor index (split over "
+                     "ranks), top-2 + ratio test, all-gather + merge"),
+}
 
-def cpu_baseline(x_sample, codebook, per_image):
+
+def cpu_baseline(x_sample, codebook, per_image, norm):
     """Oracle (numpy float64 restatement of scipy vq + np.histogram) on a row sample."""
     import oracle
     try:
@@ -46,12 +68,27 @@ def cpu_baseline(x_sample, codebook, per_image):
     code, _ = oracle.vq(x_sample, codebook)
     n_img = x_sample.shape[0] // per_image
     oracle.build_histogram([code[i * per_image:(i + 1) * per_image] for i in range(n_img)],
-                           codebook.shape[0], "l2")
+                           codebook.shape[0], norm)
     dt = time.perf_counter() - t0
     return {"value": x_sample.shape[0] / dt, "unit": "assignments/s", "cores": int(cores),
             "kind": "port",
-            "sample": "%d of the %d rows (same codebook, float64 numpy GEMM + argmin + np.histogram), "
-                      "%.1f s" % (x_sample.shape[0], N_ROWS, dt)}, code
+            "sample": "%d rows of the workload (same codebook; float64 numpy GEMM + argmin + "
+                      "np.histogram), %.1f s" % (x_sample.shape[0], dt)}, code
+
+
+def measured_traffic():
+    """HBM bytes per launch of the distance kernel from the newest committed PMC summary."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for name, rec in data.items():
+            if "k_top2_partial" in name:
+                return float(rec["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+    return None
 
 
 def main():
@@ -59,8 +96,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bow")
     ap.add_argument("--cpu-sample", type=int, default=100_000,
                     help="rows of the workload the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (smoke test)")
     args = ap.parse_args()
 
     import torch
@@ -73,26 +113,57 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from image_classification_amd import distributed as D
     from image_classification_amd import ops
-    from image_classification_amd.synthetic import sift_like_device, image_offsets
+    from image_classification_amd.backend import HipBackend
+    from image_classification_amd.synthetic import image_offsets, sift_like_device
 
-    # identical codebook on every rank, rank-specific descriptors
-    cb = sift_like_device(K_WORDS, DIM, n_modes=2048, seed=4, device=dev)
-    x = sift_like_device(N_ROWS, DIM, n_modes=2048, seed=3 + 1000 * rank, device=dev)
-    offsets = torch.from_numpy(image_offsets(N_IMAGES, N_ROWS // N_IMAGES)).to(dev)
-    cn = ops.row_sqnorm(cb)
+    w = WORKLOADS[args.workload]
+    backend = HipBackend(dev)
+    n_rows, k_words = w["rows"], w["k"]
+    flops_per_launch = None
+    units_per_step = n_rows  # what `value` counts per rank and step
 
-    def step():
-        idx, _ = ops.assign_top1(x, cb, cn, want_dist=False)
-        return idx, ops.hist(idx, offsets, K_WORDS, "l2")
+    if args.workload in ("bow", "video"):
+        cb = sift_like_device(k_words, DIM, n_modes=2048, seed=4, device=dev)
+        x = sift_like_device(n_rows, DIM, n_modes=2048, seed=3 + 1000 * rank, device=dev)
+        offsets = torch.from_numpy(image_offsets(w["images"], n_rows // w["images"])).to(dev)
+        cn = ops.row_sqnorm(cb)
+        flops_per_launch = 2.0 * n_rows * k_words * DIM
+
+        def step():
+            idx, _ = ops.assign_top1(x, cb, cn, want_dist=False)
+            return idx, ops.hist(idx, offsets, k_words, w["norm"])
+    elif args.workload == "kmeans":
+        x = sift_like_device(n_rows, DIM, n_modes=4096, seed=7 + 1000 * rank, device=dev)
+        state = {"c": sift_like_device(k_words, DIM, n_modes=4096, seed=8, device=dev)}
+        allreduce = D.make_allreduce() if use_dist else None
+        flops_per_launch = 2.0 * n_rows * k_words * DIM
+
+        def step():
+            c, labels, _ = D.lloyd(x, state["c"], 1, backend, allreduce=allreduce)
+            state["c"] = c
+            return labels, c
+    else:  # knn: the index is split over ranks, the queries are replicated
+        bounds = D.shard_bounds(k_words, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        index = sift_like_device(hi - lo, DIM, n_modes=4096, seed=6 + 1000 * rank, device=dev)
+        q = sift_like_device(n_rows, DIM, n_modes=4096, seed=5, device=dev)
+        flops_per_launch = 2.0 * n_rows * (hi - lo) * DIM
+        units_per_step = n_rows * (hi - lo)  # query x index pairs examined by this rank
+
+        def step():
+            return D.knn2_index_sharded(q, index, lo, 0.8, backend=backend)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -102,55 +173,58 @@ def main():
     ops.profile_begin(local_rank)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        idx, h = step()
+        out_a, out_b = step()[:2]
     fence()
     dt = time.perf_counter() - t0
     kern_ms, launches = ops.profile_end(local_rank)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
     if rank == 0:
-        value = world * N_ROWS * args.steps / dt_max
+        value = world * units_per_step * args.steps / dt_max
         avg_kernel_s = kern_ms / max(1, launches) / 1e3
-        flops = 2.0 * N_ROWS * K_WORDS * DIM
-        achieved = flops / avg_kernel_s / 1e12
+        achieved = flops_per_launch / avg_kernel_s / 1e12
+        is_pairs = args.workload == "knn"
         out = {
-            "metric": "descriptor->codeword assignments/sec",
+            "metric": "descriptor->codeword assignments/sec" if not is_pairs
+                      else "query-index descriptor pairs examined/sec",
             "value": value,
-            "unit": "assignments/s",
+            "unit": "assignments/s" if not is_pairs else "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if not is_pairs else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: BoW quantisation + per-image L2 histograms, "
-                                   "1M descriptors x 10k-word codebook x 128-d per GPU "
-                                   "(1000 images x 1000 descriptors)",
-                       "rows_per_gpu": N_ROWS, "codebook": K_WORDS, "dim": DIM,
-                       "images_per_gpu": N_IMAGES, "parallelism": "rows sharded, no collective"},
+            "config": {"workload": w["name"], "rows_per_gpu": n_rows,
+                       "codebook": k_words if not is_pairs else int(flops_per_launch / (2.0 * n_rows * DIM)),
+                       "dim": DIM,
+                       "parallelism": {"bow": "rows sharded, no collective",
+                                       "video": "frames sharded, no collective",
+                                       "kmeans": "rows sharded, RCCL all-reduce of sums+counts per iteration",
+                                       "knn": "index sharded, RCCL all-gather + top-2 merge"}[args.workload]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": measured_traffic() if args.workload == "bow" else None,
                          "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "flops_per_launch": flops},
+                         "flops_per_launch": flops_per_launch},
         }
-        if world == 1 and args.cpu_sample > 0:
-            ns = min(args.cpu_sample, N_ROWS)
-            per_image = N_ROWS // N_IMAGES
+        if world == 1 and args.cpu_sample > 0 and args.workload in ("bow", "video"):
+            per_image = n_rows // w["images"]
+            ns = min(args.cpu_sample, n_rows)
             ns -= ns % per_image
-            base, ref_code = cpu_baseline(x[:ns].cpu().numpy(), cb.cpu().numpy(), per_image)
-            base["agreement_with_gpu"] = float(np.mean(ref_code == idx[:ns].cpu().numpy()))
+            base, ref_code = cpu_baseline(x[:ns].cpu().numpy(), cb.cpu().numpy(), per_image, w["norm"])
+            base["agreement_with_gpu"] = float(np.mean(ref_code == out_a[:ns].cpu().numpy()))
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,6 +50,17 @@ constexpr int kRowsPerWg = kXT * kNW * 32;  // 512
 int assign_rows_per_wg() { return kRowsPerWg; }
 
 int assign_choose_nsplit(int64_t n, int64_t k, int num_cus) {
+  // IC_AMD_NSPLIT forces a split (tuning aid); it is clamped to the number of stages
+  static const int forced = [] {
+    const char* v = getenv("IC_AMD_NSPLIT");
+    return v ? atoi(v) : 0;
+  }();
+  if (forced > 0) {
+    const int64_t stages_f = (k + kStageK - 1) / kStageK;
+    const int64_t ns_f = forced < stages_f ? forced : stages_f;
+    const int64_t per_f = (stages_f + ns_f - 1) / ns_f;
+    return (int)((stages_f + per_f - 1) / per_f);
+  }
   const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
   const int64_t stages = (k + kStageK - 1) / kStageK;
   const double overhead = 2.0;  // x-tile load + pipeline fill, in units of one stage of work

@@ -202,25 +202,33 @@ __global__ __launch_bounds__(kCentThreads) void k_centroid_partials(
   __syncthreads();
 
   const int c2 = 2 * lane;
-  for (int64_t base = rbeg; base < rend; base += 64) {
-    const int64_t r = base + lane;
-    int lc = -1;
-    if (r < rend) {
-      const int64_t c = (int64_t)codes[r] - c0;
-      if (c >= 0 && c < kCR && (c & 3) == wave) lc = (int)c;
+  // the scan is latency bound unless several code loads are in flight: kScanUnroll independent
+  // 64-code loads are issued before the first is used
+  constexpr int kScanUnroll = 8;
+  for (int64_t base = rbeg; base < rend; base += 64 * kScanUnroll) {
+    int cv[kScanUnroll];
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) {
+      const int64_t r = base + u * 64 + lane;
+      cv[u] = r < rend ? codes[r] : -1;
     }
-    unsigned long long m = __ballot(lc >= 0);
-    while (m) {
-      const int e = __builtin_ctzll(m);
-      m &= m - 1;
-      const int cl = __builtin_amdgcn_readlane(lc, e);
-      const float* xrow = X + (base + e) * d;
-      double a0 = 0.0, a1 = 0.0;
-      if (c2 < d) a0 = (double)xrow[c2];
-      if (c2 + 1 < d) a1 = (double)xrow[c2 + 1];
-      sums[cl][c2] += a0;
-      sums[cl][c2 + 1] += a1;
-      if (lane == 0) cnt[cl] += 1;
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) {
+      const int64_t c = (int64_t)cv[u] - c0;
+      const int lc = (cv[u] >= 0 && c >= 0 && c < kCR && (c & 3) == wave) ? (int)c : -1;
+      unsigned long long m = __ballot(lc >= 0);
+      while (m) {  // ascending lanes = ascending rows
+        const int e = __builtin_ctzll(m);
+        m &= m - 1;
+        const int cl = __builtin_amdgcn_readlane(lc, e);
+        const float* xrow = X + (base + u * 64 + e) * d;
+        double a0 = 0.0, a1 = 0.0;
+        if (c2 < d) a0 = (double)xrow[c2];
+        if (c2 + 1 < d) a1 = (double)xrow[c2 + 1];
+        sums[cl][c2] += a0;
+        sums[cl][c2 + 1] += a1;
+        if (lane == 0) cnt[cl] += 1;
+      }
     }
   }
   __syncthreads();
