@@ -11,11 +11,11 @@ include/ic_hip.h).  Importing this package touches neither HIP nor the shared li
 from .imagedesc import ImageDesc
 from .vq import vq, kmeans2
 from .clustering import kmeans_assign, kmeans_fit
-from .features import BagOfWords, Vocabulary
-from .scene_functions import compute_vocab_features
+from .features import BagOfWords, SpatialBagOfWords, Vocabulary
+from .scene_functions import compute_spatial_features, compute_vocab_features
 from .classifiers import KNNScikit
 from .robust_matching import RobustMatcher
 
 __all__ = ["ImageDesc", "vq", "kmeans2", "kmeans_assign", "kmeans_fit", "BagOfWords",
-           "Vocabulary", "compute_vocab_features", "KNNScikit", "RobustMatcher"]
+           "SpatialBagOfWords", "Vocabulary", "compute_vocab_features", "compute_spatial_features", "KNNScikit", "RobustMatcher"]
 __version__ = "0.1.0"

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "ic_assign_top2_rec": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p],
     "ic_top2_merge": [_p, _p, _c_int, _c_i64, ctypes.POINTER(_c_i64), _p, _p, _p, _p, _c_f, _p, _p],
     "ic_hist": [_p, _p, _p, _c_i64, _c_i64, _c_int, _c_d, _p, _p],
+    "ic_spatial_hist": [_p, _p, _p, _c_i64, _c_i64, _c_int, _c_i64, _p, _p, _p],
     "ic_centroid_partials": [_p, _p, _p, _c_i64, _c_i64, _c_int, _p, _p, _p],
     "ic_centroid_finalize": [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p],
 }

@@ -50,6 +50,12 @@ class HipBackend(object):
     def hist(self, codes, offsets, k, norm="l1", power=0.5):
         return ops.hist(codes, offsets, k, norm, power)
 
+    def f64(self, a):
+        return torch.as_tensor(a, dtype=torch.float64).to(self.device)
+
+    def spatial_hist(self, codes, kp_cells, cell_weights, k):
+        return ops.spatial_hist(codes, kp_cells, cell_weights, k)
+
     def centroid_partials(self, x, codes, k):
         return ops.centroid_partials(x, codes, k)
 

@@ -335,10 +335,44 @@ int ic_hist(void* handle, const int32_t* codes, const int64_t* offsets, int64_t 
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
-  IC_HIP(ic::launch_hist(codes, offsets, n_img, k, norm_mode, power, out,
+  IC_HIP(ic::launch_hist(codes, offsets, n_img, k, norm_mode, power, nullptr, 0, out,
                          static_cast<hipStream_t>(stream)),
          "histogram kernel");
   return IC_OK;
+}
+
+int ic_spatial_hist(void* handle, const int32_t* codes, const int32_t* kp_cells, int64_t n_img,
+                    int64_t n_kp, int n_levels, int64_t k, const double* cell_weights,
+                    double* out, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_spatial_hist: invalid handle");
+  if (n_img < 0 || n_kp < 0 || k < 1 || n_levels < 1 || n_levels > 8)
+    return fail(IC_EINVAL, "ic_spatial_hist: bad shape n_img=%lld n_kp=%lld k=%lld levels=%d",
+                (long long)n_img, (long long)n_kp, (long long)k, n_levels);
+  int64_t n_cells = 0;
+  for (int l = 0, c = 1; l < n_levels; ++l, c *= 4) n_cells += c;
+  if (n_cells * k > 0x7fffffffLL)
+    return fail(IC_EINVAL, "ic_spatial_hist: %lld cells x %lld words exceeds int32 keys",
+                (long long)n_cells, (long long)k);
+  if (n_img == 0) return IC_OK;
+  if (!out || !cell_weights || (n_kp > 0 && (!codes || !kp_cells)))
+    return fail(IC_EINVAL, "ic_spatial_hist: NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  size_t off = 0;
+  const size_t o_keys = off; off += align_up((size_t)n_img * (size_t)n_kp * n_levels * 4 + 16);
+  const size_t o_off = off;  off += align_up((size_t)(n_img + 1) * 8);
+  int rc = ensure_ws(ctx, off);
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+  IC_HIP(ic::launch_spatial_hist(codes, kp_cells, n_img, n_kp, n_levels, k, n_cells, cell_weights,
+                                 reinterpret_cast<int32_t*>(ctx->ws + o_keys),
+                                 reinterpret_cast<int64_t*>(ctx->ws + o_off), out, s),
+         "spatial histogram kernels");
+  return finish_call(ctx, s);
 }
 
 int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int64_t n, int64_t k,

@@ -38,8 +38,15 @@ hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t 
                              float* d2, float ratio, uint8_t* mask, hipStream_t s);
 
 // ---- ic_reduce.hip ---------------------------------------------------------------------------
+// cell_w (nullable): per-cell weights, bin b belongs to cell b / cell_k (raw counts only).
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
-                       int norm_mode, double power, double* out, hipStream_t s);
+                       int norm_mode, double power, const double* cell_w, int64_t cell_k,
+                       double* out, hipStream_t s);
+// keys [n_img * n_kp * n_levels] int32 and offsets [n_img + 1] int64 are workspace.
+hipError_t launch_spatial_hist(const int32_t* codes, const int32_t* kp_cells, int64_t n_img,
+                               int64_t n_kp, int n_levels, int64_t k, int64_t n_cells,
+                               const double* cell_w, int32_t* keys, int64_t* offsets, double* out,
+                               hipStream_t s);
 
 // Decomposition of the centroid-sum kernel: clusters per workgroup and number of row ranges.
 void centroid_plan(int64_t n, int64_t k, int num_cus, int* n_rr);

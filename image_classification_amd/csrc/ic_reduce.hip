@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
                                                        const int64_t* __restrict__ offsets,
                                                        int64_t k, int bins_per_wg, int norm_mode,
                                                        double power, int fused_norm,
-                                                       double* __restrict__ out) {
+                                                       const double* __restrict__ cell_w,
+                                                       int64_t cell_k, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned hsm[];
   __shared__ double red[kHistThreads / 64];
   const int tid = threadIdx.x;
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
   __syncthreads();
 
   double* orow = out + img * k + bin0;
+  if (cell_w) {  // spatial pyramid: raw counts scaled by the weight of the bin's cell
+    for (unsigned b = tid; b < nb; b += kHistThreads)
+      orow[b] = (double)hist[b] * cell_w[(bin0 + b) / cell_k];
+    return;
+  }
   if (!fused_norm) {  // raw counts; k_hist_normalise finishes rows that span several workgroups
     for (unsigned b = tid; b < nb; b += kHistThreads) orow[b] = (double)hist[b];
     return;
@@ -151,7 +157,8 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_normalise(int64_t k, int 
 }
 
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
-                       int norm_mode, double power, double* out, hipStream_t s) {
+                       int norm_mode, double power, const double* cell_w, int64_t cell_k,
+                       double* out, hipStream_t s) {
   if (n_img <= 0) return hipSuccess;
   const int bins_per_wg = k < kHistMaxBins ? (int)k : kHistMaxBins;
   const int64_t n_ranges = (k + bins_per_wg - 1) / bins_per_wg;
@@ -163,15 +170,59 @@ hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_i
   if (e != hipSuccess) return e;
   const int fused = n_ranges == 1 ? 1 : 0;
   hipLaunchKernelGGL(k_hist, dim3((unsigned)n_img, (unsigned)n_ranges), dim3(kHistThreads), lds, s,
-                     codes, offsets, k, bins_per_wg, norm_mode, power, fused, out);
+                     codes, offsets, k, bins_per_wg, norm_mode, power, fused, cell_w, cell_k, out);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (!fused && norm_mode != IC_NORM_NONE) {
+  if (!fused && norm_mode != IC_NORM_NONE && !cell_w) {
     hipLaunchKernelGGL(k_hist_normalise, dim3((unsigned)n_img), dim3(kHistThreads), 0, s, k,
                        norm_mode, power, out);
     e = hipGetLastError();
   }
   return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spatial pyramid.  Every keypoint votes once per pyramid level, into the cell it falls in on that
+// level; with the cells numbered 0 .. n_cells-1 over all levels this is an ordinary histogram over
+// the keys  cell * k + code  with n_levels keys per keypoint, so k_hist does the counting and
+// applies the per-cell weight.  Replaces _get_spatial_histogram / compute_spatial_features
+// (vision/utils/scene_functions.py:279-373 of the reference).
+__global__ __launch_bounds__(256) void k_spatial_keys(const int32_t* __restrict__ codes,
+                                                      const int32_t* __restrict__ kp_cells,
+                                                      int64_t n_img, int64_t n_kp, int n_levels,
+                                                      int64_t k, int32_t* __restrict__ keys,
+                                                      int64_t* __restrict__ offsets) {
+  const int64_t per_img = n_kp * n_levels;
+  const int64_t total = n_img * per_img;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * 256) {
+    const int64_t img = t / per_img;
+    const int64_t rem = t - img * per_img;
+    const int64_t kp = rem / n_levels;
+    const int lev = (int)(rem - kp * n_levels);
+    const int32_t code = codes[img * n_kp + kp];
+    const int32_t cell = kp_cells[(int64_t)lev * n_kp + kp];
+    keys[t] = (code >= 0 && code < k && cell >= 0) ? (int32_t)(cell * k + code) : -1;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= n_img;
+       i += (int64_t)gridDim.x * 256)
+    offsets[i] = i * per_img;
+}
+
+hipError_t launch_spatial_hist(const int32_t* codes, const int32_t* kp_cells, int64_t n_img,
+                               int64_t n_kp, int n_levels, int64_t k, int64_t n_cells,
+                               const double* cell_w, int32_t* keys, int64_t* offsets, double* out,
+                               hipStream_t s) {
+  if (n_img <= 0) return hipSuccess;
+  const int64_t total = n_img * n_kp * n_levels;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_spatial_keys, dim3((unsigned)grid), dim3(256), 0, s, codes, kp_cells, n_img,
+                     n_kp, n_levels, k, keys, offsets);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_hist(keys, offsets, n_img, n_cells * k, IC_NORM_NONE, 0.5, cell_w, k, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ from .backend import default_backend
 from .clustering import kmeans_fit
 from .imagedesc import ImageDesc
 
-__all__ = ["BagOfWords", "Vocabulary"]
+__all__ = ["BagOfWords", "SpatialBagOfWords", "Vocabulary"]
 
 
 class Vocabulary(object):
@@ -243,3 +243,45 @@ class BagOfWords(object):
     @staticmethod
     def _feat_path(model_dir):
         return os.path.join(model_dir, "feat_ext")
+
+
+class SpatialBagOfWords(BagOfWords):
+    """Bag of words with a spatial pyramid (model/features.py:1287-1326): every image has the same
+    keypoint grid, and the histogram is `compute_spatial_features` over the codes of all images."""
+    _attrs_to_save = ["n_levels", "im_height", "im_width"]
+
+    def __init__(self, n_levels, im_height, im_width, feat_ext, vocabsize=None, vocab=None,
+                 projection=None, backend=None):
+        super(SpatialBagOfWords, self).__init__(feat_ext, vocabsize=vocabsize, vocab=vocab,
+                                                projection=projection, backend=backend)
+        self.n_levels = n_levels
+        self.im_height = im_height
+        self.im_width = im_width
+
+    def _build_histogram(self, image_descs, codebooks):
+        from .scene_functions import compute_spatial_features
+        if image_descs:
+            # keypoints are the same for all images; keypoint.pt is (row, col), (col, row) is needed
+            cv_kps = image_descs[0].cv_keypoints
+            kps = np.asarray([(k.pt if hasattr(k, "pt") else k)[::-1] for k in cv_kps])
+            return compute_spatial_features(np.asarray(codebooks), kps, len(self.vocab),
+                                            self.n_levels, self.im_width, self.im_height,
+                                            backend=getattr(self, "_backend", None))
+        return []
+
+    def save_to_dir(self, model_dir):
+        super(SpatialBagOfWords, self).save_to_dir(model_dir)
+        params = {attr: getattr(self, attr) for attr in self._attrs_to_save}
+        with open(self._params_path(model_dir), "wb") as f:
+            pickle.dump(params, f)
+
+    @classmethod
+    def get_state(cls, model_dir):
+        state = BagOfWords.get_state(model_dir)
+        with open(SpatialBagOfWords._params_path(model_dir), "rb") as f:
+            state.update(pickle.load(f))
+        return state
+
+    @staticmethod
+    def _params_path(model_dir):
+        return os.path.join(model_dir, "params")

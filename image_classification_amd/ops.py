@@ -147,6 +147,29 @@ def hist(codes, offsets, k, norm="l1", power=0.5):
     return out
 
 
+def spatial_hist(codes, kp_cells, cell_weights, k):
+    """codes int32 [n_img, n_kp], kp_cells int32 [n_levels, n_kp], cell_weights float64 [n_cells]
+    -> float64 [n_img, n_cells * k] weighted spatial-pyramid counts."""
+    if codes.dtype != torch.int32 or kp_cells.dtype != torch.int32 or codes.dim() != 2:
+        raise ValueError("codes must be int32 [n_img, n_kp] and kp_cells int32 [n_levels, n_kp]")
+    if kp_cells.dim() != 2 or kp_cells.shape[1] != codes.shape[1]:
+        raise ValueError("kp_cells must have one column per keypoint")
+    if cell_weights.dtype != torch.float64:
+        raise ValueError("cell_weights must be float64")
+    dev = _dev_index(codes)
+    n_img, n_kp = codes.shape
+    n_levels = kp_cells.shape[0]
+    n_cells = sum(4 ** l for l in range(n_levels))
+    if cell_weights.shape[0] != n_cells:
+        raise ValueError("need %d cell weights for %d levels" % (n_cells, n_levels))
+    out = torch.empty((n_img, n_cells * int(k)), dtype=torch.float64, device=codes.device)
+    rc = _lib.load().ic_spatial_hist(_lib.handle(dev), _ptr(codes.contiguous()),
+                                     _ptr(kp_cells.contiguous()), n_img, n_kp, n_levels, int(k),
+                                     _ptr(cell_weights.contiguous()), _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, "ic_spatial_hist")
+    return out
+
+
 def centroid_partials(x, codes, k):
     """sums float64 [k, d] and counts int64 [k] of the rows of x grouped by code."""
     _check_2d_f32(x, "x")

@@ -106,6 +106,18 @@ int ic_top2_merge(void* handle, const ic_top2_rec* gathered, int n_shards, int64
 int ic_hist(void* handle, const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
             int norm_mode, double power, double* out, void* stream);
 
+/* Spatial-pyramid histogram.  Replaces _get_spatial_histogram + compute_spatial_features
+ * (vision/utils/scene_functions.py:279-373): every keypoint adds 1 to bin (cell, code) of the
+ * cell it falls in on each pyramid level, and the counts of a cell are multiplied by the cell's
+ * weight.  The keypoint grid is shared by all images (model/features.py:1301-1304), so the
+ * caller passes the cell of every keypoint on every level.
+ *   codes [n_img][n_kp] int32, kp_cells [n_levels][n_kp] int32 (cell numbers 0 .. n_cells-1 with
+ *   n_cells = sum 4^l, a negative cell skips the vote), cell_weights [n_cells] float64 (device),
+ *   out [n_img][n_cells * k] float64, cells in ascending order, k words each. */
+int ic_spatial_hist(void* handle, const int32_t* codes, const int32_t* kp_cells, int64_t n_img,
+                    int64_t n_kp, int n_levels, int64_t k, const double* cell_weights,
+                    double* out, void* stream);
+
 /* k-means update step, part 1: sums[j] = sum of rows with codes[i] == j (float64), counts[j] =
  * number of them.  Replaces scipy's _vq.update_cluster_means inside kmeans2
  * (vision/facerec/face_indexing.py:158).  Deterministic: fixed summation order, no atomics.

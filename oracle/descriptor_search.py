@@ -3,7 +3,7 @@ import numpy as np
 
 __all__ = ["sq_distances", "vq", "compute_vocab_features", "topk", "kneighbors",
            "ratio_matches", "robust_match_descriptors", "build_histogram", "hist_normalise",
-           "update_cluster_means", "kmeans2_matrix", "top2_merge"]
+           "update_cluster_means", "kmeans2_matrix", "top2_merge", "compute_spatial_features"]
 
 
 def sq_distances(x, c):
@@ -179,3 +179,41 @@ def top2_merge(shard_results, shard_base):
     order = np.lexsort((key_i, dist), axis=1)[:, :2]
     rows = np.arange(dist.shape[0])[:, None]
     return dist[rows, order], ind[rows, order]
+
+
+def _get_spatial_histogram(vocab_feat, keypoints, vocab_size, num_levels, im_width, im_height,
+                           num_cells):
+    """vision/utils/scene_functions.py:279-307, statement by statement (a Python loop over the
+    keypoints; level 0 is cell 0, deeper cells are numbered column-major after a running base)."""
+    num_images = vocab_feat.shape[0]
+    counts_mat = np.zeros((num_images, num_cells, vocab_size))
+    image_range = np.arange(num_images)
+    for kp_id, kp in enumerate(keypoints):
+        vocab_for_kp = vocab_feat[:, kp_id]
+        col, row = kp[0], kp[1]
+        counts_mat[image_range, 0, vocab_for_kp] += 1
+        base_cell_count = 0
+        for level in range(1, num_levels):
+            base_cell_count += 4 ** (level - 1)
+            row_div = im_height / (2. ** level)
+            col_div = im_width / (2. ** level)
+            grid_pos = (int(row / row_div), int(col / col_div))
+            cell_id = base_cell_count + (2 ** level) * grid_pos[1] + grid_pos[0]
+            counts_mat[image_range, cell_id, vocab_for_kp] += 1
+    return counts_mat
+
+
+def compute_spatial_features(vocab_feat, keypoints, vocab_size, num_levels, im_width, im_height):
+    """vision/utils/scene_functions.py:338-373: weighted pyramid counts, one row per image."""
+    cell_weights = np.asarray([pow(2, 1 - num_levels)] +
+                              sum([[pow(2, -i)] * pow(4, num_levels - i)
+                                   for i in range(num_levels - 1, 0, -1)], []))
+    num_cells = len(cell_weights)
+    num_images = vocab_feat.shape[0]
+    features = np.zeros((num_images, num_cells * vocab_size))
+    feature_mat = _get_spatial_histogram(vocab_feat, keypoints, vocab_size, num_levels, im_width,
+                                         im_height, num_cells)
+    for image_id, mat in enumerate(feature_mat):
+        weighted_mat = mat * cell_weights[:, np.newaxis]
+        features[image_id, :] = np.hstack(weighted_mat)
+    return features

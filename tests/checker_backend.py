@@ -95,6 +95,22 @@ class CheckerBackend(object):
         per = [c[off[i]:off[i + 1]] for i in range(len(off) - 1)]
         return torch.from_numpy(oracle.build_histogram(per, int(k), norm, power).reshape(len(per), int(k)))
 
+    def f64(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+    def spatial_hist(self, codes, kp_cells, cell_weights, k):
+        c = codes.numpy().astype(np.int64)
+        cells = kp_cells.numpy()
+        w = cell_weights.numpy()
+        out = np.zeros((c.shape[0], len(w), int(k)))
+        rows = np.arange(c.shape[0])
+        for lev in range(cells.shape[0]):
+            for kp in range(cells.shape[1]):
+                if cells[lev, kp] >= 0:
+                    out[rows, cells[lev, kp], c[:, kp]] += 1
+        out *= w[None, :, None]
+        return torch.from_numpy(out.reshape(c.shape[0], -1))
+
     def centroid_partials(self, x, codes, k):
         _, _, sums, counts = oracle.update_cluster_means(x.numpy(), codes.numpy().astype(np.int64), int(k))
         return torch.from_numpy(sums), torch.from_numpy(counts.astype(np.int64))

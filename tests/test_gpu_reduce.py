@@ -114,6 +114,24 @@ def test_centroid_partials_vs_oracle(n, k, d):
     assert oracle.check_close(new_c, ref_c, rel=1e-6, abs_floor=1e-3) <= 1e-6
 
 
+@pytest.mark.parametrize("k,levels,n_img", [(500, 3, 9), (10000, 3, 4), (64, 4, 3), (7, 1, 2)])
+def test_spatial_pyramid_vs_reference_loop(k, levels, n_img):
+    from image_classification_amd.scene_functions import (spatial_cell_weights,
+                                                          spatial_keypoint_cells)
+    rng = np.random.default_rng(k + levels)
+    cols = np.arange(7, 800, 15)
+    rows = np.arange(7, 400, 15)
+    kps = np.asarray([(c, r) for c in cols for r in rows], dtype=np.float64)
+    codes = rng.integers(0, k, size=(n_img, len(kps))).astype(np.int32)
+    cells = spatial_keypoint_cells(kps, levels, 800, 400)
+    w = spatial_cell_weights(levels)
+    got = ops.spatial_hist(torch.from_numpy(codes).cuda(), torch.from_numpy(cells).cuda(),
+                           torch.from_numpy(w).cuda(), k)
+    torch.cuda.synchronize()
+    ref = oracle.compute_spatial_features(codes, kps, k, levels, 800, 400)
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
 def test_config2_full_size_properties():
     """1M x 10k x 128 on one GPU: properties that need no CPU oracle at this size."""
     dev = torch.device("cuda")

@@ -296,3 +296,46 @@ def test_kmeans2_argument_errors(backend):
         kmeans2(x, 11, minit="points", backend=backend)
     with pytest.raises(ValueError):
         kmeans2(x, 3, missing="ignore", backend=backend)
+
+
+# ---- spatial pyramid ----------------------------------------------------------------------------
+def _grid_keypoints(width, height, intv):
+    cols = np.arange(intv // 2, width, intv)
+    rows = np.arange(intv // 2, height, intv)
+    return np.asarray([(c, r) for c in cols for r in rows], dtype=np.float64)  # (col, row)
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3])
+def test_compute_spatial_features_matches_reference_loop(backend, levels):
+    from image_classification_amd import compute_spatial_features
+    rng = np.random.default_rng(levels)
+    kps = _grid_keypoints(800, 400, 45)
+    k = 37
+    vocab_feat = rng.integers(0, k, size=(5, len(kps)))
+    got = compute_spatial_features(vocab_feat, kps, k, levels, 800, 400, backend=backend)
+    ref = oracle.compute_spatial_features(vocab_feat, kps, k, levels, 800, 400)
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    assert np.array_equal(got, ref)       # counts times powers of two: exact
+    n_cells = sum(4 ** l for l in range(levels))
+    assert got.shape[1] == n_cells * k
+    # every level holds every keypoint once: level sums are n_kp times the level weight
+    assert np.allclose(got[:, :k].sum(1), len(kps) * 2.0 ** (1 - levels))
+
+
+def test_spatial_bag_of_words_end_to_end(backend):
+    from image_classification_amd import SpatialBagOfWords
+    from image_classification_amd.synthetic import sift_like
+    rng = np.random.default_rng(12)
+    kps = _grid_keypoints(160, 80, 20)                 # (col, row)
+    pts = [(r, c) for c, r in kps]                     # cv2-style .pt order is (row, col) here
+    vocab = sift_like(24, seed=90).astype(np.float64)
+    codes = rng.integers(0, 24, size=(4, len(kps)))
+    per_image = []
+    for i in range(4):
+        desc = (vocab[codes[i]] + rng.normal(0, 0.5, size=(len(kps), 128))).astype(np.float32)
+        per_image.append((pts, desc))
+    sbow = SpatialBagOfWords(3, 80, 160, FakeExtractor(per_image), vocab=vocab, backend=backend)
+    descs, feats = sbow.extract([0, 1, 2, 3])
+    ref = oracle.compute_spatial_features(codes, kps, 24, 3, 160, 80)
+    assert feats.shape == (4, 21 * 24) and np.array_equal(feats, ref)
+    assert sbow._build_histogram([], []) == []
