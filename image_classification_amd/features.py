@@ -55,6 +55,21 @@ class Vocabulary(object):
         self.vocab = centers.astype(np.float64)
         return self.vocab
 
+    def _write_to_file(self, feats):
+        """Descriptor file pair in a temporary location (model/features.py:1357-1365)."""
+        from tempfile import mkstemp
+        from .bovw_files import write_descriptor_file
+        h, feat_file = mkstemp()
+        os.close(h)
+        os.unlink(feat_file)
+        return write_descriptor_file(feat_file + ".xml", feats)
+
+    def _read_vocab(self, vocab_file):
+        """float64 [vocab_size, dim] from `<vocab_file>.desc` (model/features.py:1335-1341)."""
+        from .bovw_files import binary_to_ndarray
+        return binary_to_ndarray(vocab_file + ".desc", (self.vocab_size, self.dim),
+                                 np.float32).astype(np.float64)
+
     def save_to_file(self, file_path):
         assert self.vocab is not None, "Vocabulary is missing"
         with open(file_path, "wb") as f:

@@ -127,7 +127,31 @@ def g6_cvf():
     save("g6_cvf", vocab=vocab, feat=feat, codes=codes)
 
 
+def g7_files():
+    """The descriptor file pair exactly as Vocabulary._write_xml / _write_to_file produce it
+    (model/features.py:1343-1365): same XMLGenerator calls, same tag order, float32 payload."""
+    import io
+    from xml.sax.saxutils import XMLGenerator
+    feats = sift_like(5, d=6, n_modes=2, seed=20240615).astype(np.float64)
+    out = io.StringIO()
+    w = XMLGenerator(out=out, encoding="utf-8")
+    w.startDocument()
+    w.startElement("opencv_storage", {})
+    w.startElement("cols", {})
+    w.characters(str(feats.shape[1]))
+    w.endElement("cols")
+    w.startElement("nDescriptors", {})
+    w.characters(str(feats.shape[0]))
+    w.endElement("nDescriptors")
+    w.endElement("opencv_storage")
+    w.endDocument()
+    xml = np.frombuffer(out.getvalue().encode("utf-8"), dtype=np.uint8)
+    desc = np.frombuffer(feats.astype(np.float32).tobytes(), dtype=np.uint8)
+    save("g7_files", feats=feats, xml=xml, desc=desc)
+
+
 if __name__ == "__main__":
+    g7_files()
     g1_vq()
     g2_ties()
     g3_hist()

@@ -1,0 +1,65 @@
+"""The `.xml` / `.desc` file contract of the reference's BoVW binaries and the vocab_kms stand-in."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from image_classification_amd import bovw_files
+from image_classification_amd.features import Vocabulary
+from image_classification_amd.synthetic import sift_like
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_descriptor_file_bytes_match_reference_writer(tmp_path):
+    g = np.load(os.path.join(GOLDEN, "g7_files.npz"), allow_pickle=False)
+    path = str(tmp_path / "feats.xml")
+    bovw_files.write_descriptor_file(path, g["feats"])
+    assert open(path, "rb").read() == g["xml"].tobytes()
+    assert open(path + ".desc", "rb").read() == g["desc"].tobytes()
+    back = bovw_files.read_descriptor_file(path)
+    assert back.dtype == np.float32 and np.array_equal(back, g["feats"].astype(np.float32))
+    assert bovw_files.extract_from_xml(path, ["cols", "nDescriptors"]) == [6, 5]
+    with pytest.raises(AssertionError):
+        bovw_files.extract_from_xml(path, ["numCenters"])
+
+
+def test_vocab_file_round_trip_and_vocabulary_helpers(tmp_path):
+    centers = sift_like(7, d=16, n_modes=3, seed=1).astype(np.float64)
+    path = str(tmp_path / "vocab.xml")
+    bovw_files.write_vocab_file(path, centers)
+    assert bovw_files.extract_from_xml(path, ["numCenters", "dimension"]) == [7, 16]
+    v32 = bovw_files.read_vocab_file(path)
+    v64 = bovw_files.read_vocab_file(path, as_float64=True)
+    assert v32.dtype == np.float32 and v64.dtype == np.float64
+    assert np.array_equal(v32, centers.astype(np.float32)) and np.array_equal(v64, v32)
+    voc = Vocabulary(7)
+    voc.dim = 16
+    assert np.array_equal(voc._read_vocab(path), v64)      # float64, as the reference returns it
+    feat_file = voc._write_to_file(centers)
+    try:
+        assert feat_file.endswith(".xml")
+        assert np.array_equal(bovw_files.read_descriptor_file(feat_file), v32)
+    finally:
+        os.unlink(feat_file)
+        os.unlink(feat_file + ".desc")
+
+
+def test_vocab_kms_file_to_file(backend, tmp_path):
+    feats = sift_like(600, n_modes=6, seed=2)
+    fin = str(tmp_path / "projected.xml")
+    fout = str(tmp_path / "vocab.xml")
+    bovw_files.write_descriptor_file(fin, feats)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bovw_files.vocab_kms("/unused/bin", fin, 6, fout, iterations=8, seed=3, backend=backend)
+    vocab = bovw_files.read_vocab_file(fout)
+    assert vocab.shape == (6, 128) and np.isfinite(vocab).all()
+    # every centre is the mean of the descriptors assigned to it in the last iteration, so it
+    # lies inside the data's bounding box
+    assert (vocab.min() >= feats.min() - 1e-3) and (vocab.max() <= feats.max() + 1e-3)
+    with pytest.raises(IOError):
+        bovw_files.vocab_kms(None, fin, 601, fout, backend=backend)     # more codes than rows
+    with pytest.raises(IOError):
+        bovw_files.vocab_kms(None, str(tmp_path / "missing.xml"), 6, fout, backend=backend)
