@@ -11,6 +11,11 @@ from . import device as _device
 from . import ops
 
 
+def _as_f32_rows(a):
+    import numpy as np
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 class HipBackend(object):
     name = "hip-gfx950"
 
@@ -33,6 +38,19 @@ class HipBackend(object):
 
     def codebook(self, c):
         return _device.resident(c, self.device)
+
+    # -- searches whose rows start in host memory (numpy): streamed upload -----------------------
+    def assign_top1_np(self, x_np, cb, want_dist=True):
+        x_np = _as_f32_rows(x_np)
+        if x_np.shape[0] <= ops.HOST_CHUNK_ROWS:
+            return self.assign_top1(self.f32(x_np), cb, want_dist)
+        return ops.assign_from_host(x_np, cb.c, cb.sqnorm, top2=False, want_dist=want_dist)
+
+    def assign_top2_np(self, x_np, cb, ratio=0.8):
+        x_np = _as_f32_rows(x_np)
+        if x_np.shape[0] <= ops.HOST_CHUNK_ROWS:
+            return self.assign_top2(self.f32(x_np), cb, ratio)
+        return ops.assign_from_host(x_np, cb.c, cb.sqnorm, top2=True, ratio=ratio)
 
     # -- operators -----------------------------------------------------------------------------
     def assign_top1(self, x, cb, want_dist=True):

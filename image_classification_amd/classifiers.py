@@ -73,7 +73,7 @@ class KNNScikit(object):
         if features.shape[0] == 0:
             ind = np.empty((0, neighbors), dtype=np.int64)
             return (np.empty((0, neighbors), dtype=np.float64), ind) if dist else ind
-        i1, d1, i2, d2, _ = b.assign_top2(b.f32(features), self._cb)
+        i1, d1, i2, d2, _ = b.assign_top2_np(features, self._cb)
         if neighbors == 1:
             ind = i1.cpu().numpy().astype(np.int64)[:, None]
             dd = d1.cpu().numpy().astype(np.float64)[:, None]

@@ -18,9 +18,11 @@ from .backend import default_backend
 def kmeans_assign(x, codebook, backend=None, return_dist=False):
     """Nearest-codeword index (int32) of every row of x; optionally the Euclidean distance."""
     b = backend or default_backend()
-    xd = b.f32(x)
     cb = b.codebook(codebook)
-    idx, dist = b.assign_top1(xd, cb, want_dist=return_dist)
+    if isinstance(x, np.ndarray):
+        idx, dist = b.assign_top1_np(x, cb, want_dist=return_dist)
+    else:
+        idx, dist = b.assign_top1(b.f32(x), cb, want_dist=return_dist)
     idx = idx.cpu().numpy()
     if return_dist:
         return idx, dist.cpu().numpy()

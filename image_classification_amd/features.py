@@ -147,7 +147,7 @@ class BagOfWords(object):
         if not parts:
             return b.i32(np.empty(0, dtype=np.int32)), offsets
         allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
-        codes, _ = b.assign_top1(b.f32(allx), b.codebook(self.vocab), want_dist=False)
+        codes, _ = b.assign_top1_np(allx, b.codebook(self.vocab), want_dist=False)
         return codes, offsets
 
     def _quantize(self, image_descs):

@@ -5,6 +5,7 @@ numpy-in / numpy-out mirrors of the reference's call sites (vq.py, features.py, 
 robust_matching.py, scene_functions.py) are thin layers over these functions.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -66,34 +67,93 @@ def _check_pair(x, c):
         raise ValueError("x and codebook live on different devices")
 
 
-def assign_top1(x, c, c_sqnorm=None, want_dist=True):
-    """idx[i] = argmin_j |x_i - c_j| (lowest j on ties), dist[i] = that Euclidean distance."""
+def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None):
+    """idx[i] = argmin_j |x_i - c_j| (lowest j on ties), dist[i] = that Euclidean distance.
+    `out` = (idx, dist) preallocated contiguous device tensors (views are fine)."""
     _check_pair(x, c)
     dev = _dev_index(x)
     n = x.shape[0]
-    idx = torch.empty(n, dtype=torch.int32, device=x.device)
-    dist = torch.empty(n, dtype=torch.float32, device=x.device) if want_dist else None
+    if out is not None:
+        idx, dist = out
+    else:
+        idx = torch.empty(n, dtype=torch.int32, device=x.device)
+        dist = torch.empty(n, dtype=torch.float32, device=x.device) if want_dist else None
     rc = _lib.load().ic_assign_top1(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
                                     _ptr(c_sqnorm), _ptr(idx), _ptr(dist), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top1")
     return idx, dist
 
 
-def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True):
-    """Two nearest rows of c per row of x, ascending (distance, index), and the ratio-test mask."""
+def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True, out=None):
+    """Two nearest rows of c per row of x, ascending (distance, index), and the ratio-test mask.
+    `out` = (i1, d1, i2, d2, mask) preallocated contiguous device tensors."""
     _check_pair(x, c)
     dev = _dev_index(x)
     n = x.shape[0]
-    i1 = torch.empty(n, dtype=torch.int32, device=x.device)
-    i2 = torch.empty(n, dtype=torch.int32, device=x.device)
-    d1 = torch.empty(n, dtype=torch.float32, device=x.device)
-    d2 = torch.empty(n, dtype=torch.float32, device=x.device)
-    mask = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None
+    if out is not None:
+        i1, d1, i2, d2, mask = out
+    else:
+        i1 = torch.empty(n, dtype=torch.int32, device=x.device)
+        i2 = torch.empty(n, dtype=torch.int32, device=x.device)
+        d1 = torch.empty(n, dtype=torch.float32, device=x.device)
+        d2 = torch.empty(n, dtype=torch.float32, device=x.device)
+        mask = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None
     rc = _lib.load().ic_assign_top2(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
                                     _ptr(c_sqnorm), _ptr(i1), _ptr(d1), _ptr(i2), _ptr(d2),
                                     float(ratio), _ptr(mask), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top2")
     return i1, d1, i2, d2, mask
+
+
+_copy_streams = {}
+HOST_CHUNK_ROWS = 1 << 17   # rows per upload chunk of the streamed host path (64 MiB of float32)
+
+
+def _copy_stream(device):
+    key = (os.getpid(), str(device))
+    s = _copy_streams.get(key)
+    if s is None:
+        s = _copy_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+def assign_from_host(x_np, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=True,
+                     chunk_rows=None):
+    """Search rows that live in HOST memory (numpy float32 [n, d], C-contiguous).
+
+    The rows are uploaded in chunks on a second stream while the previous chunk is being searched
+    on the current stream, so the PCIe transfer hides behind the kernel instead of preceding it.
+    Returns what assign_top1 / assign_top2 return (device tensors covering all rows).
+    """
+    chunk_rows = int(chunk_rows or HOST_CHUNK_ROWS)
+    n = x_np.shape[0]
+    device = c.device
+    if top2:
+        outs = (torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.float32, device=device),
+                torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.float32, device=device),
+                torch.empty(n, dtype=torch.uint8, device=device))
+    else:
+        outs = (torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.float32, device=device) if want_dist else None)
+    cur = torch.cuda.current_stream(device)
+    side = _copy_stream(device)
+    side.wait_stream(cur)
+    for lo in range(0, n, chunk_rows):
+        hi = min(n, lo + chunk_rows)
+        with torch.cuda.stream(side):
+            xd = torch.from_numpy(x_np[lo:hi]).to(device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        cur.wait_event(ready)
+        xd.record_stream(cur)
+        view = tuple(o[lo:hi] if o is not None else None for o in outs)
+        if top2:
+            assign_top2(xd, c, ratio, c_sqnorm, out=view)
+        else:
+            assign_top1(xd, c, c_sqnorm, want_dist, out=view)
+    return outs
 
 
 def assign_top2_rec(x, c, c_sqnorm=None):

@@ -69,7 +69,7 @@ class RobustMatcher(object):
             parts.append(np.asarray(image_list[n].descriptors, dtype=np.float32))
             rows.append(rows[-1] + parts[-1].shape[0])
         allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
-        i1, _d1, _i2, _d2, mask = b.assign_top2(b.f32(allx), b.codebook(query.descriptors),
+        i1, _d1, _i2, _d2, mask = b.assign_top2_np(allx, b.codebook(query.descriptors),
                                                 ratio=self.knn_thresh)
         i1 = i1.cpu().numpy()
         mask = mask.cpu().numpy().astype(bool)

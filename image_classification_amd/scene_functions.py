@@ -25,7 +25,7 @@ def compute_vocab_features(vocab, feat, backend=None):
     if feat.shape[0] == 0:
         return np.zeros(0, dtype=np.int64)
     b = backend or default_backend()
-    idx, _ = b.assign_top1(b.f32(feat), b.codebook(vocab), want_dist=False)
+    idx, _ = b.assign_top1_np(feat, b.codebook(vocab), want_dist=False)
     return idx.cpu().numpy().astype(np.int64)
 
 

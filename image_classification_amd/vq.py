@@ -35,7 +35,11 @@ def vq(obs, code_book, check_finite=True, backend=None):
     if obs_a.shape[1] != cb_a.shape[1]:
         raise ValueError("Code book(%d) and obs(%d) should have the same number of features "
                          "(e.g. columns)" % (cb_a.shape[1], obs_a.shape[1]))
-    if check_finite and not (np.isfinite(obs_a).all() and np.isfinite(cb_a).all()):
+    # scipy scans both arrays on the host first.  For a large observation matrix that scan costs
+    # more than the whole device search, so it is replaced by a check of the result: with a finite
+    # code book, a row holds an inf or NaN exactly when its distance is not finite.
+    big = obs_a.size > (1 << 22)
+    if check_finite and not (np.isfinite(cb_a).all() and (big or np.isfinite(obs_a).all())):
         raise ValueError("array must not contain infs or NaNs")
     ct = np.result_type(obs_a.dtype, cb_a.dtype)
     if ct.kind != "f":
@@ -43,8 +47,11 @@ def vq(obs, code_book, check_finite=True, backend=None):
     if obs_a.shape[0] == 0:
         return np.empty(0, dtype=np.int32), np.empty(0, dtype=ct)
     b = backend or default_backend()
-    idx, dist = b.assign_top1(b.f32(obs_a), b.codebook(cb_a), want_dist=True)
-    return idx.cpu().numpy(), dist.cpu().numpy().astype(ct)
+    idx, dist = b.assign_top1_np(obs_a, b.codebook(cb_a), want_dist=True)
+    dist = dist.cpu().numpy()
+    if check_finite and big and not np.isfinite(dist).all():
+        raise ValueError("array must not contain infs or NaNs")
+    return idx.cpu().numpy(), dist.astype(ct)
 
 
 def kmeans2(data, k, iter=10, thresh=1e-5, minit="points", missing="warn", check_finite=True,

@@ -57,6 +57,12 @@ class CheckerBackend(object):
         idx = torch.from_numpy(i[:, 0].astype(np.int32))
         return idx, (torch.from_numpy(d[:, 0].astype(np.float32)) if want_dist else None)
 
+    def assign_top1_np(self, x_np, cb, want_dist=True):
+        return self.assign_top1(self.f32(x_np), cb, want_dist)
+
+    def assign_top2_np(self, x_np, cb, ratio=0.8):
+        return self.assign_top2(self.f32(x_np), cb, ratio)
+
     def assign_top2(self, x, cb, ratio=0.8):
         d, i = self._top(x, cb, 2)
         d32 = d.astype(np.float32)

@@ -150,6 +150,34 @@ def test_merge_of_index_shards_equals_unsharded():
     assert torch.equal(md1.cpu()[same], d1.cpu()[same])
 
 
+def test_streamed_host_path_equals_device_path():
+    # numpy rows are uploaded chunk by chunk on a side stream while the previous chunk is searched
+    x = sift_like(300_001, seed=61)
+    c = sift_like(700, seed=62)
+    cd = _dev(c)
+    cn = ops.row_sqnorm(cd)
+    idx_d, dist_d = ops.assign_top1(_dev(x), cd, cn)
+    idx_h, dist_h = ops.assign_from_host(x, cd, cn, top2=False, chunk_rows=65536)
+    torch.cuda.synchronize()
+    assert torch.equal(idx_d, idx_h) and torch.equal(dist_d, dist_h)
+    t_d = ops.assign_top2(_dev(x), cd, 0.8, cn)
+    t_h = ops.assign_from_host(x, cd, cn, top2=True, ratio=0.8, chunk_rows=100_000)
+    torch.cuda.synchronize()
+    for a, b in zip(t_d, t_h):
+        assert torch.equal(a, b)
+    from image_classification_amd import vq
+    code, dist = vq(x, c.astype(np.float64))
+    assert np.array_equal(code, idx_d.cpu().numpy())
+    # large inputs are checked for infs / NaNs through the result instead of a host scan
+    bad = x.copy()
+    bad[250_000, 5] = np.nan
+    with pytest.raises(ValueError):
+        vq(bad, c.astype(np.float64))
+    bad[250_000, 5] = np.inf
+    with pytest.raises(ValueError):
+        vq(bad, c.astype(np.float64))
+
+
 def test_errors_are_loud():
     x = _dev(np.zeros((4, 128)))
     with pytest.raises(ValueError):

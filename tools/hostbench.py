@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the numpy-in / numpy-out API (PCIe included): hostbench.py [N] [K]."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from image_classification_amd import vq  # noqa: E402
+from image_classification_amd.synthetic import sift_like  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+x = sift_like(n, n_modes=2048, seed=3)
+c = sift_like(k, n_modes=2048, seed=4).astype(np.float64)
+vq(x[:1000], c)  # library load, handle, codebook upload
+torch.cuda.synchronize()
+for rep in range(3):
+    t0 = time.perf_counter()
+    code, dist = vq(x, c, check_finite=False)
+    t1 = time.perf_counter()
+    print("vq(%d x %d) numpy in/out: %.1f ms -> %.3g assignments/s (PCIe included)"
+          % (n, k, (t1 - t0) * 1e3, n / (t1 - t0)), flush=True)
+t0 = time.perf_counter()
+xd = torch.from_numpy(x).cuda()
+torch.cuda.synchronize()
+print("pageable H2D of %.0f MB: %.1f ms" % (x.nbytes / 1e6, (time.perf_counter() - t0) * 1e3))
+xp = torch.from_numpy(x).pin_memory()
+t0 = time.perf_counter()
+xd = xp.cuda(non_blocking=True)
+torch.cuda.synchronize()
+print("pinned   H2D of %.0f MB: %.1f ms" % (x.nbytes / 1e6, (time.perf_counter() - t0) * 1e3))
+t0 = time.perf_counter()
+ok = np.isfinite(x).all()
+print("np.isfinite check: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
