@@ -387,19 +387,36 @@ int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
-  int n_rr = 1;
-  ic::centroid_plan(n, k, ctx->num_cus, &n_rr);
-  size_t off = 0;
-  const size_t o_ps = off; if (n_rr > 1) off += align_up((size_t)n_rr * (size_t)k * d * 8);
-  const size_t o_pc = off; if (n_rr > 1) off += align_up((size_t)n_rr * (size_t)k * 8);
-  int rc = ensure_ws(ctx, off);
+  if (n == 0) {
+    IC_HIP(hipMemsetAsync(sums, 0, (size_t)k * d * 8, s), "hipMemsetAsync");
+    IC_HIP(hipMemsetAsync(counts, 0, (size_t)k * 8, s), "hipMemsetAsync");
+    return IC_OK;
+  }
+  ic::CentroidPlan plan;
+  ic::centroid_plan(n, k, d, ctx->num_cus, &plan);
+  if (plan.use_scan) {
+    int n_rr = 1;
+    ic::centroid_plan_scan(n, k, ctx->num_cus, &n_rr);
+    size_t off = 0;
+    const size_t o_ps = off; if (n_rr > 1) off += align_up((size_t)n_rr * (size_t)k * d * 8);
+    const size_t o_pc = off; if (n_rr > 1) off += align_up((size_t)n_rr * (size_t)k * 8);
+    int rc = ensure_ws(ctx, off);
+    if (rc) return rc;
+    rc = order_after_previous(ctx, s);
+    if (rc) return rc;
+    IC_HIP(ic::launch_centroid_partials_scan(x, codes, n, k, d, n_rr,
+                                             reinterpret_cast<double*>(ctx->ws + o_ps),
+                                             reinterpret_cast<int64_t*>(ctx->ws + o_pc), sums,
+                                             counts, s),
+           "centroid sums kernel (scan)");
+    return finish_call(ctx, s);
+  }
+  int rc = ensure_ws(ctx, plan.bytes);
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
-  IC_HIP(ic::launch_centroid_partials(x, codes, n, k, d, n_rr,
-                                      reinterpret_cast<double*>(ctx->ws + o_ps),
-                                      reinterpret_cast<int64_t*>(ctx->ws + o_pc), sums, counts, s),
-         "centroid sums kernel");
+  IC_HIP(ic::launch_centroid_partials(x, codes, n, k, d, plan, ctx->ws, sums, counts, s),
+         "centroid sums kernels");
   return finish_call(ctx, s);
 }
 

@@ -48,11 +48,29 @@ hipError_t launch_spatial_hist(const int32_t* codes, const int32_t* kp_cells, in
                                const double* cell_w, int32_t* keys, int64_t* offsets, double* out,
                                hipStream_t s);
 
-// Decomposition of the centroid-sum kernel: clusters per workgroup and number of row ranges.
-void centroid_plan(int64_t n, int64_t k, int num_cus, int* n_rr);
+// ---- ic_centroid.hip -------------------------------------------------------------------------
+// Decomposition and workspace layout of the partition-based centroid sums.
+struct CentroidPlan {
+  int64_t nblk;      // 4096-row sort blocks
+  int64_t nb;        // buckets of 32 clusters
+  int n_ranges;      // chunk ranges per bucket (partial sums folded afterwards)
+  bool use_scan;     // table too large: fall back to the scan-based kernel
+  size_t o_keys, o_tab, tab_bytes, o_total, o_start, o_perm, o_psums, o_pcounts, bytes;
+};
+void centroid_plan(int64_t n, int64_t k, int d, int num_cus, CentroidPlan* p);
 hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_t n, int64_t k,
-                                    int d, int n_rr, double* part_sums, int64_t* part_counts,
-                                    double* sums, int64_t* counts, hipStream_t s);
+                                    int d, const CentroidPlan& p, char* ws, double* sums,
+                                    int64_t* counts, hipStream_t s);
+
+// ---- ic_reduce.hip (continued) ----------------------------------------------------------------
+void centroid_plan_scan(int64_t n, int64_t k, int num_cus, int* n_rr);
+hipError_t launch_centroid_partials_scan(const float* x, const int32_t* codes, int64_t n,
+                                         int64_t k, int d, int n_rr, double* part_sums,
+                                         int64_t* part_counts, double* sums, int64_t* counts,
+                                         hipStream_t s);
+hipError_t launch_centroid_reduce(const double* part_sums, const int64_t* part_counts, int64_t k,
+                                  int d, int n_ranges, double* sums, int64_t* counts,
+                                  hipStream_t s);
 hipError_t launch_centroid_finalize(const double* sums, const int64_t* counts, const float* prev_c,
                                     int64_t k, int d, float* new_c, uint8_t* has_members,
                                     hipStream_t s);

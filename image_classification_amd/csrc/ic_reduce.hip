@@ -226,7 +226,8 @@ hipError_t launch_spatial_hist(const int32_t* codes, const int32_t* kp_cells, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Centroid sums.  Workgroup (cr, rr) owns clusters [64 cr, 64 cr + 64) over row range rr and keeps
+// Centroid sums, scan-based fallback (used only when the partition table of ic_centroid.hip
+// would not fit).  Workgroup (cr, rr) owns clusters [64 cr, 64 cr + 64) over row range rr and keeps
 // their float64 sums in LDS.  Wave w of the workgroup owns the clusters with (cluster & 3) == w: it
 // scans the range's codes 64 at a time, and for every row of one of its clusters adds the row into
 // that cluster's LDS sum (lane l adds components 2l, 2l+1).  Rows are visited in ascending order
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void k_centroid_reduce(const double* __restric
   }
 }
 
-void centroid_plan(int64_t n, int64_t k, int num_cus, int* n_rr) {
+void centroid_plan_scan(int64_t n, int64_t k, int num_cus, int* n_rr) {
   const int64_t n_cr = (k + kCR - 1) / kCR;
   int64_t rr = (4LL * num_cus + n_cr - 1) / n_cr;
   const int64_t max_rr = (n + 4095) / 4096;
@@ -318,9 +319,22 @@ void centroid_plan(int64_t n, int64_t k, int num_cus, int* n_rr) {
   *n_rr = (int)rr;
 }
 
-hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_t n, int64_t k,
-                                    int d, int n_rr, double* part_sums, int64_t* part_counts,
-                                    double* sums, int64_t* counts, hipStream_t s) {
+hipError_t launch_centroid_reduce(const double* part_sums, const int64_t* part_counts, int64_t k,
+                                  int d, int n_ranges, double* sums, int64_t* counts,
+                                  hipStream_t s) {
+  const int64_t kd = k * d;
+  int64_t grid = (kd + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_centroid_reduce, dim3((unsigned)grid), dim3(256), 0, s, part_sums,
+                     part_counts, kd, k, n_ranges, sums, counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_centroid_partials_scan(const float* x, const int32_t* codes, int64_t n,
+                                         int64_t k, int d, int n_rr, double* part_sums,
+                                         int64_t* part_counts, double* sums, int64_t* counts,
+                                         hipStream_t s) {
   const int64_t n_cr = (k + kCR - 1) / kCR;
   if (n_cr > 0x7fffffffLL) return hipErrorInvalidValue;
   int64_t rows_per = (n + n_rr - 1) / n_rr;
@@ -332,12 +346,7 @@ hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_
                      0, s, x, codes, n, k, d, rows_per, ps, pc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || n_rr == 1) return e;
-  const int64_t kd = k * d;
-  int64_t grid = (kd + 255) / 256;
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(k_centroid_reduce, dim3((unsigned)grid), dim3(256), 0, s, part_sums,
-                     part_counts, kd, k, n_rr, sums, counts);
-  return hipGetLastError();
+  return launch_centroid_reduce(part_sums, part_counts, k, d, n_rr, sums, counts, s);
 }
 
 __global__ __launch_bounds__(256) void k_centroid_finalize(const double* __restrict__ sums,

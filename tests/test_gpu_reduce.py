@@ -82,6 +82,19 @@ def test_hist_vocabulary_wider_than_one_workgroup_range():
             assert oracle.check_close(got, ref, rel=1e-12, abs_floor=1e-300) <= 1e-12
 
 
+def test_centroid_partials_skewed_codes_span_many_sort_chunks():
+    # almost every row in one cluster: its run crosses sort-chunk and row-range boundaries
+    rng = np.random.default_rng(99)
+    n, k, d = 50000, 100, 128
+    x = (rng.standard_normal((n, d)) * 50).astype(np.float32)
+    codes = np.full(n, 37, dtype=np.int32)
+    codes[rng.choice(n, size=300, replace=False)] = rng.integers(0, k, size=300)
+    sums, counts = _centroid(x, codes, k)
+    _, _, rsums, rcounts = oracle.update_cluster_means(x, codes.astype(np.int64), k)
+    assert np.array_equal(counts, rcounts)
+    assert oracle.check_close(sums, rsums, rel=1e-12, abs_floor=1e-3) <= 1e-12
+
+
 def _centroid(x, codes, k):
     s, c = ops.centroid_partials(torch.from_numpy(x).cuda(), torch.from_numpy(codes).cuda(), k)
     torch.cuda.synchronize()
@@ -89,7 +102,10 @@ def _centroid(x, codes, k):
 
 
 @pytest.mark.parametrize("n,k,d", [(5000, 32, 128), (20000, 1000, 128), (3000, 7, 64),
-                                   (100000, 65536, 128), (777, 130, 36), (64, 64, 128)])
+                                   (100000, 65536, 128), (777, 130, 36), (64, 64, 128),
+                                   (60000, 40, 128),   # few buckets: row ranges + reduce pass
+                                   (3001, 50, 37),     # odd width: scalar-load variant
+                                   (1, 1, 128)])
 def test_centroid_partials_vs_oracle(n, k, d):
     rng = np.random.default_rng(n + k)
     x = (rng.standard_normal((n, d)) * 50).astype(np.float32)
