@@ -20,8 +20,8 @@ sizing cases, run by hand for DESIGN.md, not the line the driver records):
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA distance /
 top-2 kernel): algorithmic FLOPs per launch = 2 * N * K * D, divided by its average duration
 measured with HIP events recorded on the launch stream inside the timed region; `traffic` is that
-kernel's HBM bytes per launch from the newest profiles/*_traffic.json (rocprofv3 --pmc FETCH_SIZE /
-WRITE_SIZE passes of the default workload, read side doubled as gfx950 requires).  `cpu_baseline`
+kernel's HBM bytes per launch from the newest profiles/*_<workload>_traffic.json (rocprofv3 --pmc
+FETCH_SIZE / WRITE_SIZE passes of that workload, read side doubled as gfx950 requires).  `cpu_baseline`
 (rank 0, N == 1 only) times the float64 numpy oracle on a bounded row sample of the same workload.
 """
 import argparse
@@ -76,9 +76,10 @@ def cpu_baseline(x_sample, codebook, per_image, norm):
                       "np.histogram), %.1f s" % (x_sample.shape[0], dt)}, code
 
 
-def measured_traffic():
-    """HBM bytes per launch of the distance kernel from the newest committed PMC summary."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+def measured_traffic(workload):
+    """HBM bytes per launch of the distance kernel from the newest committed PMC summary of this
+    workload (profiles/rNN_<workload>_traffic.json)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % workload)))
     if not files:
         return None
     try:
@@ -211,7 +212,7 @@ def main():
                                        "knn": "index sharded, RCCL all-gather + top-2 merge"}[args.workload]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": measured_traffic() if args.workload == "bow" else None,
+                         "traffic": measured_traffic(args.workload),
                          "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "flops_per_launch": flops_per_launch},
         }

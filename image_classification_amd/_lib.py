@@ -19,6 +19,9 @@ _handles = {}  # (pid, device) -> ctypes.c_void_p
 IC_NORM_NONE, IC_NORM_L1, IC_NORM_L2, IC_NORM_POWER_L2 = 0, 1, 2, 3
 NORM_MODES = {"none": IC_NORM_NONE, "l1": IC_NORM_L1, "l2": IC_NORM_L2,
               "power_l2": IC_NORM_POWER_L2}
+# metric names of ic_pairwise / ic_knn_rows (scikit-learn's aliases map to the same number)
+METRICS = {"euclidean": 0, "l2": 0, "sqeuclidean": 1, "manhattan": 2, "cityblock": 2, "l1": 2,
+           "intersection": 3, "chisqr": 4}
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
@@ -43,6 +46,8 @@ _SIGNATURES = {
     "ic_spatial_hist": [_p, _p, _p, _c_i64, _c_i64, _c_int, _c_i64, _p, _p, _p],
     "ic_centroid_partials": [_p, _p, _p, _c_i64, _c_i64, _c_int, _p, _p, _p],
     "ic_centroid_finalize": [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p],
+    "ic_pairwise": [_p, _p, _c_i64, _p, _c_i64, _c_int, _c_int, _p, _p],
+    "ic_knn_rows": [_p, _p, _c_i64, _p, _c_i64, _c_int, _c_int, _c_int, _p, _p, _p],
 }
 _RESTYPES = {"ic_last_error": ctypes.c_char_p}
 

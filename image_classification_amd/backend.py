@@ -80,6 +80,12 @@ class HipBackend(object):
     def centroid_finalize(self, sums, counts, prev_c):
         return ops.centroid_finalize(sums, counts, prev_c)
 
+    def pairwise(self, x, c, metric="euclidean"):
+        return ops.pairwise(x, c, metric)
+
+    def knn_rows(self, x, c, k, metric="euclidean"):
+        return ops.knn_rows(x, c, k, metric)
+
     def make_codebook(self, c_dev):
         """Wrap a device tensor produced by centroid_finalize as a codebook."""
         return _device.ResidentCodebook(c_dev, self.device)

@@ -1,20 +1,50 @@
-"""`KNNScikit` with the reference's interface, brute-force Euclidean search on the device.
+"""`KNNScikit` with the reference's interface, brute-force search on the device.
 
 Mirrors model/classifiers.py:165-197: `KNNScikit(neighbors, metric, weights, **kw)`,
 `train(features, labels)` fits once (later calls are ignored, the `_is_trained` guard at :175),
 `get_neighbors(features, neighbors, dist=True)` returns what
 `KNeighborsClassifier.kneighbors(features, n_neighbors, return_distance)` returns: distances
-float64 [M, k] ascending and indices int64 [M, k], or the indices alone.
+float64 [M, k] ascending and indices int64 [M, k], or the indices alone.  `test` and
+`test_probability` (:180-193) vote over the neighbour lists as scikit-learn does.
 
-Only what the descriptor-matching path uses is implemented: metric 'euclidean' (or 'minkowski'
-with p=2) and at most two neighbours (model/robust_matching.py:73-80).  Anything else raises
-NotImplementedError rather than running on the CPU.
+Two searches sit behind it:
+  * Euclidean, width <= 128, at most two neighbours (the descriptor matching of
+    model/robust_matching.py:73-80): the matrix-core distance / top-2 kernel;
+  * everything else (bag-of-words histograms of any width, 'manhattan' as configured in
+    vision/logo_recognition/training.py:41, the `intersection` / `chisqr` functions of
+    model/clustering.py passed as `metric`, more neighbours): distance matrix + row top-k.
+Metrics without a device kernel raise NotImplementedError rather than running on the CPU.
 """
 import numpy as np
 
+from . import clustering as _clustering
 from .backend import default_backend
 
 __all__ = ["KNNScikit"]
+
+_STRING_METRICS = {"euclidean": "euclidean", "l2": "euclidean", "manhattan": "manhattan",
+                   "cityblock": "manhattan", "l1": "manhattan", "sqeuclidean": "sqeuclidean"}
+
+
+def _device_metric(metric, kwargs):
+    if callable(metric):
+        if metric is _clustering.intersection:
+            return "intersection"
+        if metric is _clustering.chisqr:
+            return "chisqr"
+        raise NotImplementedError("only the `intersection` and `chisqr` functions of this package "
+                                  "are supported as callable metrics")
+    if metric == "minkowski":
+        p = kwargs.get("p", 2)
+        if p == 2:
+            return "euclidean"
+        if p == 1:
+            return "manhattan"
+        raise NotImplementedError("minkowski is supported for p = 1 and p = 2 only")
+    if metric in _STRING_METRICS:
+        return _STRING_METRICS[metric]
+    raise NotImplementedError("KNNScikit on the device supports euclidean, manhattan, sqeuclidean, "
+                              "intersection and chisqr (got %r)" % (metric,))
 
 
 class KNNScikit(object):
@@ -29,10 +59,9 @@ class KNNScikit(object):
         self._backend = backend
         self._fit_X = None
         self._cb = None
-        p = distance_kwargs.get("p", 2)
-        if not (metric == "euclidean" or (metric == "minkowski" and p == 2)):
-            raise NotImplementedError("KNNScikit on the device supports the euclidean metric only "
-                                      "(got %r)" % (metric,))
+        self._metric = _device_metric(metric, distance_kwargs)
+        if weights not in ("distance", "uniform"):
+            raise NotImplementedError("weights must be 'distance' or 'uniform'")
 
     def _b(self):
         return self._backend or default_backend()
@@ -48,6 +77,7 @@ class KNNScikit(object):
                                  "[%d, %d]" % (features.shape[0], len(labels)))
             self.labels_map = sorted(list(set(labels)))
             self._labels = np.asarray(labels)
+            self.classes_ = np.asarray(self.labels_map)
             self._fit_X = features
             self._cb = self._b().codebook(features)
             self._is_trained = True
@@ -63,8 +93,6 @@ class KNNScikit(object):
             raise ValueError("Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, "
                              "n_samples_fit = %d, n_samples = %d"
                              % (neighbors, n_fit, np.asarray(features).shape[0]))
-        if neighbors > 2:
-            raise NotImplementedError("the device search returns at most 2 neighbours")
         features = np.asarray(features)
         if features.ndim != 2 or features.shape[1] != self._fit_X.shape[1]:
             raise ValueError("X has %s features, but KNNScikit is expecting %d features as input."
@@ -73,14 +101,55 @@ class KNNScikit(object):
         if features.shape[0] == 0:
             ind = np.empty((0, neighbors), dtype=np.int64)
             return (np.empty((0, neighbors), dtype=np.float64), ind) if dist else ind
-        i1, d1, i2, d2, _ = b.assign_top2_np(features, self._cb)
-        if neighbors == 1:
-            ind = i1.cpu().numpy().astype(np.int64)[:, None]
-            dd = d1.cpu().numpy().astype(np.float64)[:, None]
+        if self._metric == "euclidean" and neighbors <= 2 and features.shape[1] <= 128:
+            i1, d1, i2, d2, _ = b.assign_top2_np(features, self._cb)
+            if neighbors == 1:
+                ind = i1.cpu().numpy().astype(np.int64)[:, None]
+                dd = d1.cpu().numpy().astype(np.float64)[:, None]
+            else:
+                ind = np.stack([i1.cpu().numpy(), i2.cpu().numpy()], axis=1).astype(np.int64)
+                dd = np.stack([d1.cpu().numpy(), d2.cpu().numpy()], axis=1).astype(np.float64)
         else:
-            ind = np.stack([i1.cpu().numpy(), i2.cpu().numpy()], axis=1).astype(np.int64)
-            dd = np.stack([d1.cpu().numpy(), d2.cpu().numpy()], axis=1).astype(np.float64)
+            dd, ind = b.knn_rows(b.f32(features), self._cb.c, neighbors, self._metric)
+            dd = dd.cpu().numpy()
+            ind = ind.cpu().numpy().astype(np.int64)
         return (dd, ind) if dist else ind
 
+    # -- label votes over the neighbour lists (host side: [M, k] arrays) ---------------------------
+    def _votes(self, features):
+        dd, ind = self.get_neighbors(features, self.n_neighbors, dist=True)
+        w = np.ones_like(dd)
+        if self.weights == "distance":
+            with np.errstate(divide="ignore"):
+                w = 1.0 / dd
+            zero = np.isinf(w)
+            rows = zero.any(axis=1)
+            w[rows] = zero[rows].astype(np.float64)
+        col = np.searchsorted(self.classes_, self._labels[ind])
+        votes = np.zeros((dd.shape[0], len(self.classes_)), dtype=np.float64)
+        rows = np.arange(dd.shape[0])
+        for j in range(ind.shape[1]):
+            np.add.at(votes, (rows, col[:, j]), w[:, j])
+        return votes
+
+    def predict_proba(self, features):
+        votes = self._votes(features)
+        s = votes.sum(axis=1, keepdims=True)
+        s[s == 0] = 1.0
+        return votes / s
+
     def test(self, features):
-        raise NotImplementedError("label prediction is outside the descriptor-matching path")
+        """Predicted label per row: the class with the largest vote, lowest class on ties."""
+        return self.classes_[np.argmax(self._votes(features), axis=1)]
+
+    def test_probability(self, features, min_prob_diff):
+        """Best label when its probability leads the runner-up by `min_prob_diff`, else -1
+        (model/classifiers.py:183-193)."""
+        y_pred = []
+        for row in self.predict_proba(features):
+            idx = row.argsort()
+            if row[idx[-1]] - row[idx[-2]] >= min_prob_diff:
+                y_pred.append(self.labels_map[idx[-1]])
+            else:
+                y_pred.append(-1)
+        return y_pred

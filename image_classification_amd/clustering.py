@@ -106,3 +106,29 @@ def kmeans_fit(x, k, iters=10, minit="points", missing="warn", rng=None, backend
     c, labels, _ = lloyd(xd, b.f32(init), iters, b, on_empty=on_empty)
     out_dtype = x.dtype if x.dtype.kind == "f" else np.float64
     return c.cpu().numpy().astype(out_dtype), labels.cpu().numpy()
+
+
+# ---- histogram comparison functions of the reference's clustering module -------------------------
+def _hist_compare(p1, p2, metric, backend=None):
+    """One value of a histogram metric between two 1-D histograms (model/clustering.py:313-320:
+    both are converted to float32, the value comes back as a Python float)."""
+    p1 = np.asarray(p1)
+    p2 = np.asarray(p2)
+    if p1.ndim != 1 or p1.shape != p2.shape:
+        raise ValueError("expected two 1-D histograms of the same length, got %s and %s"
+                         % (p1.shape, p2.shape))
+    b = backend or default_backend()
+    return float(b.pairwise(b.f32(p1[None, :]), b.f32(p2[None, :]), metric).cpu().numpy()[0, 0])
+
+
+def chisqr(p1, p2):
+    """Chi-square histogram distance sum((p1-p2)^2 / p1) (model/clustering.py:305-306).
+    `KNNScikit(metric=chisqr)` recognises this function and runs the batched device kernel."""
+    return _hist_compare(p1, p2, "chisqr")
+
+
+def intersection(p1, p2):
+    """Histogram intersection sum(min(p1, p2)) (model/clustering.py:309-310).
+    `KNNScikit(metric=intersection)` recognises this function and runs the batched device
+    kernel; like the reference, the neighbour search treats the value as a distance."""
+    return _hist_compare(p1, p2, "intersection")

@@ -436,4 +436,59 @@ int ic_centroid_finalize(void* handle, const double* sums, const int64_t* counts
   return IC_OK;
 }
 
+int ic_pairwise(void* handle, const float* x, int64_t m, const float* c, int64_t n, int d,
+                int metric, double* out, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_pairwise: invalid handle");
+  if (m < 0 || n < 0 || d < 1 || metric < IC_METRIC_EUCLIDEAN || metric > IC_METRIC_CHISQR)
+    return fail(IC_EINVAL, "ic_pairwise: bad argument m=%lld n=%lld d=%d metric=%d", (long long)m,
+                (long long)n, d, metric);
+  if (m == 0 || n == 0) return IC_OK;
+  if (!x || !c || !out) return fail(IC_EINVAL, "ic_pairwise: NULL pointer");
+  if (m > (int64_t)65535 * 64)
+    return fail(IC_EINVAL, "ic_pairwise: at most %d search rows per call", 65535 * 64);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  IC_HIP(ic::launch_pairdist(x, m, c, n, d, metric, out, static_cast<hipStream_t>(stream)),
+         "pairwise distance kernel");
+  return IC_OK;
+}
+
+int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t n, int d,
+                int metric, int k, double* out_dist, int32_t* out_idx, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_knn_rows: invalid handle");
+  if (m < 0 || n < 1 || d < 1 || metric < IC_METRIC_EUCLIDEAN || metric > IC_METRIC_CHISQR)
+    return fail(IC_EINVAL, "ic_knn_rows: bad argument m=%lld n=%lld d=%d metric=%d", (long long)m,
+                (long long)n, d, metric);
+  if (k < 1 || k > n)
+    return fail(IC_EINVAL, "ic_knn_rows: need 1 <= k <= n, got k=%d n=%lld", k, (long long)n);
+  if (n > 0x7fffffffLL) return fail(IC_EINVAL, "ic_knn_rows: index rows exceed int32");
+  if (m == 0) return IC_OK;
+  if (!x || !c || !out_dist || !out_idx) return fail(IC_EINVAL, "ic_knn_rows: NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  // the distance matrix of one block of search rows lives in the workspace (at most ~1 GiB)
+  int64_t rows = ((int64_t)1 << 30) / (n * 8);
+  if (rows < 1) rows = 1;
+  if (rows > m) rows = m;
+  if (rows > 65535 * 64) rows = 65535 * 64;
+  int rc = ensure_ws(ctx, align_up((size_t)rows * (size_t)n * 8));
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+  double* dist = reinterpret_cast<double*>(ctx->ws);
+  for (int64_t r0 = 0; r0 < m; r0 += rows) {
+    const int64_t mr = m - r0 < rows ? m - r0 : rows;
+    IC_HIP(ic::launch_pairdist(x + r0 * d, mr, c, n, d, metric, dist, s),
+           "pairwise distance kernel");
+    IC_HIP(ic::launch_topk_rows(dist, mr, n, k, out_dist + r0 * k, out_idx + r0 * k, s),
+           "row top-k kernel");
+  }
+  return finish_call(ctx, s);
+}
+
 }  // extern "C"

@@ -75,4 +75,10 @@ hipError_t launch_centroid_finalize(const double* sums, const int64_t* counts, c
                                     int64_t k, int d, float* new_c, uint8_t* has_members,
                                     hipStream_t s);
 
+// ---- ic_knn.hip ------------------------------------------------------------------------------
+hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n, int d, int metric,
+                           double* out, hipStream_t s);
+hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, double* out_d,
+                            int32_t* out_i, hipStream_t s);
+
 }  // namespace ic

@@ -1,0 +1,208 @@
+// Brute-force k nearest rows in a feature space of any width under a histogram metric
+// (Euclidean, L1, histogram intersection, chi-square).  This is the shortlist search over
+// bag-of-words histograms (vision/logo_recognition/knn_training.py:24-60 trains it,
+// model/classifiers.py:195-197 queries it); none of these metrics except the Euclidean one is a
+// matrix product, so the kernels are plain VALU work staged through LDS:
+//
+//   k_pairdist<METRIC>  64 x 64 tile of the distance matrix per workgroup, 4 x 4 per lane,
+//                       32 components per LDS stage, f32 inside a stage, f64 across stages
+//   k_topk_rows         one workgroup per search row: k rounds of "smallest (distance, index)
+//                       pair above the previous one", so ties resolve to the lowest index
+#include "ic_internal.h"
+
+namespace ic {
+
+namespace {
+
+constexpr int kTile = 64;      // rows of either operand per workgroup tile
+constexpr int kChunk = 32;     // components per LDS stage
+constexpr int kLdsStride = 68; // floats per staged component (64 rows + pad, keeps 16-byte alignment)
+constexpr int kPairThreads = 256;
+constexpr int kTopkThreads = 256;
+
+template <int METRIC>
+__device__ __forceinline__ float pair_term(float a, float b) {
+  if (METRIC == IC_METRIC_L1) return fabsf(a - b);
+  if (METRIC == IC_METRIC_INTERSECTION) return fminf(a, b);
+  if (METRIC == IC_METRIC_CHISQR) {
+    // OpenCV's CV_COMP_CHISQR: bins whose first operand is (numerically) zero are skipped
+    const float t = a - b;
+    return fabsf(a) > 2.2204460492503131e-16f ? t * t / a : 0.f;
+  }
+  const float t = a - b;
+  return t * t;
+}
+
+// stage rows [r0, r0+64) x components [d0, d0+32) of `src` into lds[comp][row]; zero outside
+__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t rows, int d,
+                                           int64_t r0, int d0, float* lds) {
+#pragma unroll
+  for (int e = 0; e < kTile * kChunk / kPairThreads; ++e) {
+    const int idx = threadIdx.x + e * kPairThreads;
+    const int row = idx / kChunk, col = idx % kChunk;
+    const int64_t gr = r0 + row;
+    const int gc = d0 + col;
+    const bool ok = gr < rows && gc < d;
+    const float v = src[ok ? gr * d + gc : 0];
+    lds[col * kLdsStride + row] = ok ? v : 0.f;
+  }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(kPairThreads) void k_pairdist(
+    const float* __restrict__ x, int64_t m, const float* __restrict__ c, int64_t n, int d,
+    double* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float xs[kChunk * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float cs[kChunk * kLdsStride];
+  const int64_t c0 = (int64_t)blockIdx.x * kTile;
+  const int64_t x0 = (int64_t)blockIdx.y * kTile;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+
+  for (int d0 = 0; d0 < d; d0 += kChunk) {
+    __syncthreads();
+    stage_tile(x, m, d, x0, d0, xs);
+    stage_tile(c, n, d, c0, d0, cs);
+    __syncthreads();
+    float part[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[i][j] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < kChunk; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&xs[kk * kLdsStride + ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&cs[kk * kLdsStride + tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[i][j] += pair_term<METRIC>(av[i], bv[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += (double)part[i][j];
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = x0 + ty * 4 + i;
+    if (r >= m) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = c0 + tx * 4 + j;
+      if (col < n) out[r * n + col] = METRIC == IC_METRIC_EUCLIDEAN ? sqrt(acc[i][j]) : acc[i][j];
+    }
+  }
+}
+
+struct DistIdx {
+  double d;
+  int32_t i;
+};
+
+__device__ __forceinline__ bool pair_less(double d, int32_t i, double e, int32_t j) {
+  return d < e || (d == e && i < j);
+}
+
+// dist [m][n] -> the k smallest (distance, index) pairs of every row, ascending.
+__global__ __launch_bounds__(kTopkThreads) void k_topk_rows(
+    const double* __restrict__ dist, int64_t n, int k, double* __restrict__ out_d,
+    int32_t* __restrict__ out_i) {
+  __shared__ double sd[kTopkThreads / 64];
+  __shared__ int32_t si[kTopkThreads / 64];
+  __shared__ double last_d;
+  __shared__ int32_t last_i;
+  const double* row = dist + (int64_t)blockIdx.x * n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double prev_d = -__builtin_inf();
+  int32_t prev_i = -1;
+  for (int r = 0; r < k; ++r) {
+    double best_d = __builtin_inf();
+    int32_t best_i = 0x7fffffff;
+    for (int64_t j = threadIdx.x; j < n; j += kTopkThreads) {
+      const double v = row[j];
+      const int32_t ji = (int32_t)j;
+      const bool above = pair_less(prev_d, prev_i, v, ji);
+      const bool better = pair_less(v, ji, best_d, best_i);
+      if (above && better) {
+        best_d = v;
+        best_i = ji;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(best_d, off);
+      const int32_t oi = __shfl_xor(best_i, off);
+      if (pair_less(od, oi, best_d, best_i)) {
+        best_d = od;
+        best_i = oi;
+      }
+    }
+    if (lane == 0) {
+      sd[wave] = best_d;
+      si[wave] = best_i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double bd = sd[0];
+      int32_t bi = si[0];
+      for (int w = 1; w < kTopkThreads / 64; ++w)
+        if (pair_less(sd[w], si[w], bd, bi)) {
+          bd = sd[w];
+          bi = si[w];
+        }
+      last_d = bd;
+      last_i = bi;
+      out_d[(int64_t)blockIdx.x * k + r] = bd;
+      out_i[(int64_t)blockIdx.x * k + r] = bi == 0x7fffffff ? -1 : bi;
+    }
+    __syncthreads();
+    prev_d = last_d;
+    prev_i = last_i;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n, int d, int metric,
+                           double* out, hipStream_t s) {
+  const dim3 grid((unsigned)((n + kTile - 1) / kTile), (unsigned)((m + kTile - 1) / kTile));
+  const dim3 block(kPairThreads);
+  switch (metric) {
+    case IC_METRIC_EUCLIDEAN:
+      hipLaunchKernelGGL(k_pairdist<IC_METRIC_EUCLIDEAN>, grid, block, 0, s, x, m, c, n, d, out);
+      break;
+    case IC_METRIC_SQEUCLIDEAN:
+      hipLaunchKernelGGL(k_pairdist<IC_METRIC_SQEUCLIDEAN>, grid, block, 0, s, x, m, c, n, d, out);
+      break;
+    case IC_METRIC_L1:
+      hipLaunchKernelGGL(k_pairdist<IC_METRIC_L1>, grid, block, 0, s, x, m, c, n, d, out);
+      break;
+    case IC_METRIC_INTERSECTION:
+      hipLaunchKernelGGL(k_pairdist<IC_METRIC_INTERSECTION>, grid, block, 0, s, x, m, c, n, d, out);
+      break;
+    case IC_METRIC_CHISQR:
+      hipLaunchKernelGGL(k_pairdist<IC_METRIC_CHISQR>, grid, block, 0, s, x, m, c, n, d, out);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, double* out_d,
+                            int32_t* out_i, hipStream_t s) {
+  hipLaunchKernelGGL(k_topk_rows, dim3((unsigned)m), dim3(kTopkThreads), 0, s, dist, n, k, out_d,
+                     out_i);
+  return hipGetLastError();
+}
+
+}  // namespace ic

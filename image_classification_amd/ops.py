@@ -261,6 +261,41 @@ def centroid_finalize(sums, counts, prev_c):
     return new_c, has
 
 
+def _metric_number(metric):
+    if metric not in _lib.METRICS:
+        raise ValueError("metric must be one of %s, got %r" % (sorted(_lib.METRICS), metric))
+    return _lib.METRICS[metric]
+
+
+def pairwise(x, c, metric="euclidean"):
+    """float64 [m, n] matrix of `metric` between the rows of x [m, d] and c [n, d] (float32)."""
+    _check_2d_f32(x, "x")
+    _check_2d_f32(c, "c")
+    if x.shape[1] != c.shape[1] or x.shape[1] < 1:
+        raise ValueError("dimension mismatch: x has %d columns, c %d" % (x.shape[1], c.shape[1]))
+    dev = _dev_index(x)
+    out = torch.empty((x.shape[0], c.shape[0]), dtype=torch.float64, device=x.device)
+    rc = _lib.load().ic_pairwise(_lib.handle(dev), _ptr(x), x.shape[0], _ptr(c), c.shape[0],
+                                 x.shape[1], _metric_number(metric), _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, "ic_pairwise")
+    return out
+
+
+def knn_rows(x, c, k, metric="euclidean"):
+    """(dist float64 [m, k], idx int32 [m, k]): the k rows of c nearest to every row of x,
+    ascending by (distance, index)."""
+    _check_pair(x, c)
+    dev = _dev_index(x)
+    k = int(k)
+    dist = torch.empty((x.shape[0], k), dtype=torch.float64, device=x.device)
+    idx = torch.empty((x.shape[0], k), dtype=torch.int32, device=x.device)
+    rc = _lib.load().ic_knn_rows(_lib.handle(dev), _ptr(x), x.shape[0], _ptr(c), c.shape[0],
+                                 x.shape[1], _metric_number(metric), k, _ptr(dist), _ptr(idx),
+                                 _stream_ptr(dev))
+    _lib.check(rc, "ic_knn_rows")
+    return dist, idx
+
+
 def profile_begin(device_index):
     """Start timing the distance kernel of every following assign call on this device."""
     _lib.check(_lib.load().ic_profile_begin(_lib.handle(device_index)), "ic_profile_begin")

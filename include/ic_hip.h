@@ -39,6 +39,13 @@ extern "C" {
 #define IC_NORM_L2 2       /* count / (sqrt(sum count^2) or 1) */
 #define IC_NORM_POWER_L2 3 /* y = count^power, then y / (sqrt(sum y^2) or 1) */
 
+/* Metrics of ic_pairwise / ic_knn_rows (a = search row, b = indexed row). */
+#define IC_METRIC_EUCLIDEAN 0    /* sqrt(sum (a-b)^2)        sklearn 'euclidean'               */
+#define IC_METRIC_SQEUCLIDEAN 1  /* sum (a-b)^2                                                 */
+#define IC_METRIC_L1 2           /* sum |a-b|                sklearn 'manhattan'                */
+#define IC_METRIC_INTERSECTION 3 /* sum min(a,b)             model/clustering.py:309-310        */
+#define IC_METRIC_CHISQR 4       /* sum (a-b)^2/a over a!=0  model/clustering.py:305-306        */
+
 /* per-row partial result exchanged between shards / K-splits (16 bytes) */
 typedef struct ic_top2_rec {
   float d1;   /* best distance (Euclidean, not squared) */
@@ -131,6 +138,24 @@ int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int
 int ic_centroid_finalize(void* handle, const double* sums, const int64_t* counts,
                          const float* prev_c, int64_t k, int d, float* new_c,
                          uint8_t* has_members, void* stream);
+
+/* Distance matrix between rows of any width under one of the IC_METRIC_* metrics.  Replaces the
+ * matrix scikit-learn's brute-force neighbour search builds for KNNScikit over bag-of-words
+ * histograms (model/classifiers.py:170-172 with the metrics vision/logo_recognition/training.py:41
+ * and knn_training.py:24 configure) and scipy's cdist at vision/facerec/face_indexing.py:473.
+ *   x [m][d] f32, c [n][d] f32, out [m][n] float64 (terms in f32, accumulated in float64). */
+int ic_pairwise(void* handle, const float* x, int64_t m, const float* c, int64_t n, int d,
+                int metric, double* out, void* stream);
+
+/* The k nearest indexed rows of every search row, ascending by (distance, index).  Replaces
+ * KNeighborsClassifier.kneighbors(features, n_neighbors, return_distance) behind
+ * KNNScikit.get_neighbors (model/classifiers.py:195-197) for metrics and widths the 128-d
+ * descriptor search does not cover.  Note that IC_METRIC_INTERSECTION is a similarity: like the
+ * reference, which hands it to scikit-learn as a distance, the rows with the SMALLEST value come
+ * first.
+ *   x [m][d] f32, c [n][d] f32, 1 <= k <= n, out_dist [m][k] float64, out_idx [m][k] int32. */
+int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t n, int d,
+                int metric, int k, double* out_dist, int32_t* out_idx, void* stream);
 
 #ifdef __cplusplus
 }

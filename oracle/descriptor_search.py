@@ -3,7 +3,8 @@ import numpy as np
 
 __all__ = ["sq_distances", "vq", "compute_vocab_features", "topk", "kneighbors",
            "ratio_matches", "robust_match_descriptors", "build_histogram", "hist_normalise",
-           "update_cluster_means", "kmeans2_matrix", "top2_merge", "compute_spatial_features"]
+           "update_cluster_means", "kmeans2_matrix", "top2_merge", "compute_spatial_features",
+           "pairwise_metric", "kneighbors_metric", "knn_predict_proba"]
 
 
 def sq_distances(x, c):
@@ -217,3 +218,61 @@ def compute_spatial_features(vocab_feat, keypoints, vocab_size, num_levels, im_w
         weighted_mat = mat * cell_weights[:, np.newaxis]
         features[image_id, :] = np.hstack(weighted_mat)
     return features
+
+
+def pairwise_metric(x, c, metric="manhattan"):
+    """Distance matrix [m, n] in float64 between float32 rows under the histogram-space metrics
+    of KNNScikit (model/classifiers.py:170-172): 'euclidean', 'sqeuclidean', 'manhattan'
+    (vision/logo_recognition/training.py:41), 'intersection' = sum min(a, b) and 'chisqr' =
+    sum (a-b)^2 / a over bins with a != 0 (OpenCV compareHist, model/clustering.py:305-320; the
+    reference converts both rows to float32 first, :318-319).  Row by row: no [m, n, d] cube."""
+    x = np.asarray(x, dtype=np.float32).astype(np.float64)
+    c = np.asarray(c, dtype=np.float32).astype(np.float64)
+    out = np.empty((x.shape[0], c.shape[0]), dtype=np.float64)
+    for i in range(x.shape[0]):
+        a = x[i][None, :]
+        if metric in ("manhattan", "cityblock", "l1"):
+            out[i] = np.abs(a - c).sum(1)
+        elif metric == "intersection":
+            out[i] = np.minimum(a, c).sum(1)
+        elif metric == "chisqr":
+            keep = np.abs(x[i]) > np.finfo(np.float64).eps
+            t = a[:, keep] - c[:, keep]
+            out[i] = (t * t / a[:, keep]).sum(1)
+        elif metric in ("euclidean", "l2"):
+            out[i] = np.sqrt(((a - c) ** 2).sum(1))
+        elif metric == "sqeuclidean":
+            out[i] = ((a - c) ** 2).sum(1)
+        else:
+            raise ValueError("unknown metric %r" % (metric,))
+    return out
+
+
+def kneighbors_metric(fit_x, x, n_neighbors, metric="manhattan"):
+    """KNeighborsClassifier(metric=...).fit(fit_x).kneighbors(x, n_neighbors): the n_neighbors
+    smallest entries of every row of the distance matrix, ascending; ties by index (stable)."""
+    dist = pairwise_metric(x, fit_x, metric)
+    ind = np.argsort(dist, axis=1, kind="stable")[:, :n_neighbors]
+    return np.take_along_axis(dist, ind, axis=1), ind.astype(np.int64)
+
+
+def knn_predict_proba(neigh_dist, neigh_ind, labels, classes, weights="distance"):
+    """KNeighborsClassifier.predict_proba from the neighbour lists (model/classifiers.py:183-185):
+    every neighbour votes for its label with weight 1/distance ('distance') or 1 ('uniform'); a
+    row with zero-distance neighbours counts only those; rows are normalised to sum 1."""
+    labels = np.asarray(labels)
+    classes = list(classes)
+    w = np.ones_like(neigh_dist, dtype=np.float64)
+    if weights == "distance":
+        with np.errstate(divide="ignore"):
+            w = 1.0 / neigh_dist
+        zero = np.isinf(w)
+        rows = zero.any(axis=1)
+        w[rows] = zero[rows].astype(np.float64)
+    proba = np.zeros((neigh_dist.shape[0], len(classes)), dtype=np.float64)
+    col = np.searchsorted(np.asarray(classes), labels[neigh_ind])
+    for j in range(neigh_ind.shape[1]):
+        np.add.at(proba, (np.arange(proba.shape[0]), col[:, j]), w[:, j])
+    s = proba.sum(axis=1, keepdims=True)
+    s[s == 0] = 1.0
+    return proba / s

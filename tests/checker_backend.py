@@ -126,3 +126,12 @@ class CheckerBackend(object):
         new = prev_c.clone()
         new[has] = (sums[has] / counts[has][:, None].double()).float()
         return new, has.to(torch.uint8)
+
+    def pairwise(self, x, c, metric="euclidean"):
+        self.calls.append(("pairwise", tuple(x.shape), tuple(c.shape), metric))
+        return torch.from_numpy(oracle.pairwise_metric(x.numpy(), c.numpy(), metric))
+
+    def knn_rows(self, x, c, k, metric="euclidean"):
+        self.calls.append(("knn_rows", tuple(x.shape), tuple(c.shape), metric, k))
+        d, i = oracle.kneighbors_metric(c.numpy(), x.numpy(), k, metric)
+        return torch.from_numpy(d), torch.from_numpy(i.astype(np.int32))

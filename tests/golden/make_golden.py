@@ -15,6 +15,14 @@ golden vectors are those libraries' outputs for the reference's argument pattern
   g6_cvf         argmin(sklearn euclidean_distances(squared=True)) in vocab-sized batches
                                                                vision/utils/scene_functions.py:385-392
 
+  g8_hist_knn    KNeighborsClassifier(3, metric=..., weights='distance') over bag-of-words
+                 histograms: kneighbors / predict / predict_proba for 'manhattan' and 'euclidean',
+                 and kneighbors for a histogram-intersection callable (numpy float32 stand-in for
+                 cv2.compareHist, which is not installed; algorithm='brute' because a similarity
+                 is not a metric a tree could prune with)
+                                                               model/classifiers.py:165-197,
+                                                               vision/logo_recognition/knn_training.py:57-60
+
 Run from the repository root:  python tests/golden/make_golden.py
 Versions used for the committed files: scipy 1.15.3, scikit-learn 1.7.2, numpy 2.2.6.
 """
@@ -150,7 +158,39 @@ def g7_files():
     save("g7_files", feats=feats, xml=xml, desc=desc)
 
 
+def _intersection(p1, p2):
+    return float(np.minimum(p1.astype(np.float32), p2.astype(np.float32)).astype(np.float64).sum())
+
+
+def g8_hist_knn():
+    rng = np.random.default_rng(808)
+    n_fit, n_q, k = 300, 60, 500
+    def hists(n):
+        counts = rng.poisson(0.4, size=(n, k)).astype(np.float64)
+        counts[np.arange(n), rng.integers(0, k, size=n)] += 1     # no empty histogram
+        return counts / counts.sum(1, keepdims=True)
+    fit_x = hists(n_fit)
+    labels = rng.integers(100, 140, size=n_fit)
+    q = hists(n_q)
+    q[:5] = fit_x[[7, 7, 100, 250, 299]]                          # exact hits: zero distances
+    out = dict(fit_x=fit_x, labels=labels, q=q)
+    for metric in ("manhattan", "euclidean"):
+        knc = KNeighborsClassifier(n_neighbors=3, metric=metric, weights="distance",
+                                   algorithm="brute").fit(fit_x, labels)
+        d, i = knc.kneighbors(q, n_neighbors=3, return_distance=True)
+        d5, i5 = knc.kneighbors(q, n_neighbors=5, return_distance=True)
+        out.update({metric + "_dist": d, metric + "_ind": i, metric + "_dist5": d5,
+                    metric + "_ind5": i5, metric + "_predict": knc.predict(q),
+                    metric + "_proba": knc.predict_proba(q), metric + "_classes": knc.classes_})
+    knc = KNeighborsClassifier(n_neighbors=3, metric=_intersection, weights="distance",
+                               algorithm="brute").fit(fit_x, labels)
+    d, i = knc.kneighbors(q, n_neighbors=3, return_distance=True)
+    out.update(intersection_dist=d, intersection_ind=i)
+    save("g8_hist_knn", **out)
+
+
 if __name__ == "__main__":
+    g8_hist_knn()
     g7_files()
     g1_vq()
     g2_ties()

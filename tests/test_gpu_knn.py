@@ -1,0 +1,102 @@
+"""GPU parity of the histogram-space distance matrix and row top-k against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from image_classification_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4   # distances within 1e-4 relative; indices equal wherever the gap exceeds 1e-5 relative
+METRICS = ["euclidean", "sqeuclidean", "manhattan", "intersection", "chisqr"]
+
+
+def _hists(rng, n, d, sparse=0.4):
+    counts = rng.poisson(sparse, size=(n, d)).astype(np.float64)
+    counts[np.arange(n), rng.integers(0, d, size=n)] += 1
+    return (counts / counts.sum(1, keepdims=True)).astype(np.float32)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("m,n,d", [(1, 1, 1), (3, 5, 33), (70, 130, 64), (65, 64, 1000), (128, 257, 129)])
+def test_pairwise_vs_oracle(metric, m, n, d):
+    rng = np.random.default_rng(m * 1000 + n + d)
+    x, c = _hists(rng, m, d), _hists(rng, n, d)
+    got = ops.pairwise(_dev(x), _dev(c), metric).cpu().numpy()
+    ref = oracle.pairwise_metric(x, c, metric)
+    assert got.shape == (m, n) and got.dtype == np.float64
+    assert oracle.check_close(got, ref, abs_floor=1e-9) <= REL
+
+
+def test_pairwise_signed_rows_euclidean_and_l1():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((90, 300)).astype(np.float32) * 7
+    c = rng.standard_normal((40, 300)).astype(np.float32) * 7
+    for metric in ("euclidean", "manhattan"):
+        got = ops.pairwise(_dev(x), _dev(c), metric).cpu().numpy()
+        assert oracle.check_close(got, oracle.pairwise_metric(x, c, metric)) <= 1e-6
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_knn_rows_vs_oracle(metric):
+    rng = np.random.default_rng(17)
+    x, c = _hists(rng, 200, 700), _hists(rng, 1500, 700)
+    x[:4] = c[[3, 3, 700, 1499]]
+    k = 7
+    dist, idx = ops.knn_rows(_dev(x), _dev(c), k, metric)
+    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+    rd, ri = oracle.kneighbors_metric(c, x, k + 1, metric)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    for rank in range(k):
+        gap = (rd[:, rank + 1] - rd[:, rank]) > 1e-5 * np.maximum(np.abs(rd[:, rank + 1]), 1e-30)
+        prev_gap = np.ones(len(gap), bool) if rank == 0 else \
+            (rd[:, rank] - rd[:, rank - 1]) > 1e-5 * np.maximum(np.abs(rd[:, rank]), 1e-30)
+        must = gap & prev_gap
+        assert np.array_equal(idx[must, rank], ri[must, rank])
+    same = idx == ri[:, :k]
+    assert same.mean() > 0.99      # count histograms tie often in exact arithmetic
+    assert oracle.check_close(dist[same], rd[:, :k][same], abs_floor=1e-9) <= REL
+
+
+def test_knn_rows_ties_resolve_to_lowest_index_and_k_equals_n():
+    rng = np.random.default_rng(3)
+    base = _hists(rng, 6, 50)
+    c = np.concatenate([base, base, base[:2]])          # rows 0-5 == 6-11, rows 0,1 == 12,13
+    dist, idx = ops.knn_rows(_dev(base), _dev(c), 3, "manhattan")
+    idx = idx.cpu().numpy()
+    dist = dist.cpu().numpy()
+    assert np.array_equal(idx[:, 0], np.arange(6)) and np.array_equal(idx[:, 1], np.arange(6) + 6)
+    assert np.array_equal(idx[:2, 2], [12, 13])
+    assert np.all(dist[:, :2] == 0)
+    full_d, full_i = ops.knn_rows(_dev(base), _dev(c), c.shape[0], "manhattan")
+    assert np.array_equal(np.sort(full_i.cpu().numpy(), axis=1),
+                          np.tile(np.arange(c.shape[0]), (6, 1)))
+    rd, ri = oracle.kneighbors_metric(c, base, c.shape[0], "manhattan")
+    assert oracle.check_close(full_d.cpu().numpy(), rd, abs_floor=1e-6) <= REL
+
+
+def test_knn_rows_matches_descriptor_search_on_128d():
+    from image_classification_amd.synthetic import sift_like
+    x, c = sift_like(500, seed=1), sift_like(3000, seed=2)
+    d, i = ops.knn_rows(_dev(x), _dev(c), 2, "euclidean")
+    i1, d1, i2, d2, _ = ops.assign_top2(_dev(x), _dev(c))
+    agree = (i[:, 0] == i1) & (i[:, 1] == i2)
+    assert agree.float().mean() > 0.995
+    assert oracle.check_close(d[:, 0].cpu().numpy()[agree.cpu().numpy()],
+                              d1.cpu().numpy()[agree.cpu().numpy()]) <= REL
+
+
+def test_knn_argument_errors():
+    x = _dev(np.zeros((4, 10), np.float32))
+    c = _dev(np.zeros((3, 10), np.float32))
+    with pytest.raises(RuntimeError):
+        ops.knn_rows(x, c, 4, "manhattan")
+    with pytest.raises(ValueError):
+        ops.knn_rows(x, c, 2, "cosine")
+    with pytest.raises(ValueError):
+        ops.pairwise(x, _dev(np.zeros((3, 11), np.float32)), "manhattan")

@@ -197,16 +197,70 @@ def test_knn_scikit_get_neighbors(backend):
     assert np.array_equal(only, ind)
     d1, i1 = knn.get_neighbors(g["cand"][:10], 1)
     assert i1.shape == (10, 1) and np.array_equal(i1[:, 0], ind[:10, 0])
-    with pytest.raises(NotImplementedError):
-        knn.get_neighbors(g["cand"], 3)
+    # more than two neighbours: the general row top-k search, same two leading columns
+    d3, i3 = knn.get_neighbors(g["cand"][:200], 3)
+    assert i3.shape == (200, 3) and (i3[:, :2] == ind[:200]).all(axis=1).mean() >= 0.99
+    assert np.all(np.diff(d3, axis=1) >= 0)
     with pytest.raises(ValueError):
         knn.get_neighbors(g["cand"], 301)
     with pytest.raises(ValueError):
         knn.get_neighbors(g["cand"][:, :64], 2)
     with pytest.raises(NotImplementedError):
-        KNNScikit(2, metric="manhattan", backend=backend)
+        KNNScikit(2, metric="chebyshev", backend=backend)
+    with pytest.raises(NotImplementedError):
+        KNNScikit(2, metric=lambda a, b: 0.0, backend=backend)
     with pytest.raises(RuntimeError):
         KNNScikit(2, backend=backend).get_neighbors(g["cand"], 2)
+
+
+@pytest.mark.parametrize("metric", ["manhattan", "euclidean"])
+def test_knn_scikit_histogram_space(backend, metric):
+    # the shortlist search of the logo pipeline: bag-of-words histograms, 3 neighbours
+    g = load("g8_hist_knn")
+    knn = KNNScikit(3, metric=metric, weights="distance", backend=backend)
+    knn.train(g["fit_x"], list(g["labels"]))
+    dist, ind = knn.get_neighbors(g["q"], 3)
+    assert dist.dtype == np.float64 and ind.dtype == np.int64 and ind.shape == (60, 3)
+    assert np.array_equal(ind, g[metric + "_ind"])
+    # (scikit-learn's own Euclidean expansion leaves ~4e-9 where the distance is exactly 0)
+    assert oracle.check_close(dist, g[metric + "_dist"], abs_floor=1e-3) <= REL
+    d5, i5 = knn.get_neighbors(g["q"], 5)
+    assert np.array_equal(i5, g[metric + "_ind5"])
+    assert np.array_equal(knn.test(g["q"]), g[metric + "_predict"])
+    assert np.abs(knn.predict_proba(g["q"]) - g[metric + "_proba"]).max() <= 1e-5
+    ref = []
+    for row in g[metric + "_proba"]:
+        order = row.argsort()
+        ref.append(g[metric + "_classes"][order[-1]] if row[order[-1]] - row[order[-2]] >= 0.4
+                   else -1)
+    assert knn.test_probability(g["q"], 0.4) == ref
+
+
+def test_knn_scikit_intersection_metric_and_knn_trainer(backend):
+    from image_classification_amd.clustering import intersection
+    from image_classification_amd.knn_training import KnnTrainer
+    g = load("g8_hist_knn")
+    knn = KNNScikit(3, metric=intersection, weights="distance", algorithm="auto", backend=backend)
+    knn.train(g["fit_x"], list(g["labels"]))
+    dist, ind = knn.get_neighbors(g["q"], 3)
+    assert np.array_equal(ind, g["intersection_ind"])
+    assert oracle.check_close(dist, g["intersection_dist"], abs_floor=1e-6) <= REL
+
+    class Logo(object):
+        def __init__(self, n, label):
+            self.path, self.target_label_id = "logo%d.jpg" % n, label
+
+    class Bow(object):   # stands for BagOfWords.extract over image files
+        def extract(self, paths):
+            rows = [int(p[4:-4]) for p in paths]
+            return ["desc%d" % r for r in rows], g["fit_x"][rows]
+
+    trainer = KnnTrainer(Bow(), backend=backend)
+    trainer.train([Logo(n, int(l)) for n, l in enumerate(g["labels"])])
+    assert trainer.logos[5].image_desc == "desc5" and np.array_equal(trainer.logos[5].feature,
+                                                                     g["fit_x"][5])
+    ind2 = trainer._knnsck.get_neighbors(g["q"], 3, dist=False)
+    assert np.array_equal(ind2, g["intersection_ind"])
 
 
 def _desc(d):
