@@ -48,6 +48,9 @@ _SIGNATURES = {
     "ic_centroid_finalize": [_p, _p, _p, _p, _c_i64, _c_int, _p, _p, _p],
     "ic_pairwise": [_p, _p, _c_i64, _p, _c_i64, _c_int, _c_int, _p, _p],
     "ic_knn_rows": [_p, _p, _c_i64, _p, _c_i64, _c_int, _c_int, _c_int, _p, _p, _p],
+    "ic_compact_matches": [_p, _p, _p, _p, _c_i64, _p, _c_i64, _p, _p, _p, _p, _p, _p],
+    "ic_ransac_homography": [_p, _p, _p, _c_i64, _c_int, _p, ctypes.c_uint64, _c_d, _c_int, _c_int,
+                             _p, _p, _p, _p, _p, _p],
 }
 _RESTYPES = {"ic_last_error": ctypes.c_char_p}
 

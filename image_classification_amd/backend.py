@@ -86,6 +86,17 @@ class HipBackend(object):
     def knn_rows(self, x, c, k, metric="euclidean"):
         return ops.knn_rows(x, c, k, metric)
 
+    def u8(self, a):
+        return torch.as_tensor(a, dtype=torch.uint8).to(self.device)
+
+    def compact_matches(self, mask, i1, row_offsets, kp_query=None, kp_rows=None):
+        return ops.compact_matches(mask, i1, row_offsets, kp_query, kp_rows)
+
+    def ransac_homography(self, pts, offsets, n_iter, th, samples=None, seed=0, min_inliers=10,
+                          accept_mean_err=True):
+        return ops.ransac_homography(pts, offsets, n_iter, th, samples, seed, min_inliers,
+                                     accept_mean_err)
+
     def make_codebook(self, c_dev):
         """Wrap a device tensor produced by centroid_finalize as a codebook."""
         return _device.ResidentCodebook(c_dev, self.device)

@@ -491,4 +491,63 @@ int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t
   return finish_call(ctx, s);
 }
 
+int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
+                       const int64_t* row_offsets, int64_t n_cand, const double* kp_query,
+                       int64_t n_query, const double* kp_rows, int64_t* out_offsets,
+                       int32_t* match_q, int32_t* match_im, double* pts, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_compact_matches: invalid handle");
+  if (n_cand < 0 || n_cand > 0x7fffffffLL)
+    return fail(IC_EINVAL, "ic_compact_matches: bad candidate count %lld", (long long)n_cand);
+  if (!out_offsets) return fail(IC_EINVAL, "ic_compact_matches: out_offsets is NULL");
+  if (n_cand > 0 && (!mask || !i1 || !row_offsets || !match_q || !match_im))
+    return fail(IC_EINVAL, "ic_compact_matches: NULL pointer");
+  if (pts && (!kp_query || !kp_rows || n_query < 1))
+    return fail(IC_EINVAL, "ic_compact_matches: pts needs kp_query, kp_rows and n_query >= 1");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  if (n_cand == 0) {
+    IC_HIP(hipMemsetAsync(out_offsets, 0, 8, s), "hipMemsetAsync");
+    return IC_OK;
+  }
+  int rc = ensure_ws(ctx, align_up((size_t)n_cand * 8));
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+  IC_HIP(ic::launch_compact_matches(mask, i1, row_offsets, n_cand, kp_query, n_query, kp_rows,
+                                    reinterpret_cast<int64_t*>(ctx->ws), out_offsets, match_q,
+                                    match_im, pts, s),
+         "match compaction kernels");
+  return finish_call(ctx, s);
+}
+
+int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets, int64_t n_cand,
+                         int n_iter, const int32_t* samples, uint64_t seed, double th,
+                         int min_inliers, int accept_mean_err, double* H, int32_t* n_inliers,
+                         double* best_err, int32_t* best_iter, uint8_t* inlier_mask, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_ransac_homography: invalid handle");
+  if (n_cand < 0 || n_cand > 0x7fffffffLL || n_iter < 0 || n_iter > 65535 * 16)
+    return fail(IC_EINVAL, "ic_ransac_homography: bad size n_cand=%lld n_iter=%d",
+                (long long)n_cand, n_iter);
+  if (n_cand == 0) return IC_OK;
+  if (!pts || !offsets || !H || !n_inliers || !best_err || !inlier_mask)
+    return fail(IC_EINVAL, "ic_ransac_homography: NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  int rc = ensure_ws(ctx, align_up((size_t)n_cand * (size_t)(n_iter > 0 ? n_iter : 1) * 4));
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+  IC_HIP(ic::launch_ransac(pts, offsets, n_cand, n_iter, samples, seed, th, min_inliers,
+                           accept_mean_err, reinterpret_cast<int32_t*>(ctx->ws), H, n_inliers,
+                           best_err, best_iter, inlier_mask, s),
+         "homography RANSAC kernels");
+  return finish_call(ctx, s);
+}
+
 }  // extern "C"

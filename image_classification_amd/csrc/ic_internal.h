@@ -81,4 +81,14 @@ hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n,
 hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, double* out_d,
                             int32_t* out_i, hipStream_t s);
 
+// ---- ic_match.hip ----------------------------------------------------------------------------
+hipError_t launch_compact_matches(const uint8_t* mask, const int32_t* i1, const int64_t* row_off,
+                                  int64_t n_cand, const double* kp_q, int64_t n_q,
+                                  const double* kp_rows, int64_t* counts_ws, int64_t* out_off,
+                                  int32_t* match_q, int32_t* match_im, double* pts, hipStream_t s);
+hipError_t launch_ransac(const double* pts, const int64_t* off, int64_t n_cand, int n_iter,
+                         const int32_t* samples, uint64_t seed, double th, int min_inliers,
+                         int accept_mean_err, int32_t* n_inl_ws, double* H, int32_t* n_inliers,
+                         double* best_err, int32_t* best_it, uint8_t* mask, hipStream_t s);
+
 }  // namespace ic

@@ -1,0 +1,484 @@
+// Post-stage of the logo matcher (model/robust_matching.py:81-95 and :156-175, :291-365), batched
+// over all candidate images of a query:
+//
+//   k_count_matches / k_scan_counts / k_compact_matches
+//       ratio-test mask -> per-candidate lists of (query row, candidate row) and of matched
+//       keypoint pairs (x_q, y_q, x_im, y_im), in ascending candidate-row order (stable)
+//   k_ransac_score     one wave per (candidate, iteration): homography through the four sampled
+//                      pairs, inliers among the remaining pairs counted
+//   k_ransac_refit     one wave per candidate: first iteration with the most inliers, direct linear
+//                      transform over its inliers, mean reprojection error, acceptance, mask
+//
+// The reference's loop keeps a model only when it has strictly more inliers than the best so far and
+// stops when every pair is an inlier, so its result is that of the FIRST iteration that reaches the
+// maximum count; scoring all iterations at once and taking the first maximum gives the same answer
+// for the same samples.
+#include "ic_internal.h"
+
+namespace ic {
+
+namespace {
+
+constexpr int kItersPerWg = 16;   // iterations per workgroup of k_ransac_score (4 waves x 4)
+constexpr double kProjEps = 0.0000000001;  // "epsilon for non zero division", robust_matching.py:279
+
+// ---------------------------------------------------------------------------------------------
+// compaction
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_count_matches(const uint8_t* __restrict__ mask,
+                                                      const int64_t* __restrict__ row_off,
+                                                      int64_t* __restrict__ counts) {
+  const int64_t c = blockIdx.x;
+  const int64_t r0 = row_off[c], r1 = row_off[c + 1];
+  int cnt = 0;
+  for (int64_t j = r0 + threadIdx.x; j < r1; j += 64) cnt += mask[j] != 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (threadIdx.x == 0) counts[c] = cnt;
+}
+
+// out[0] = 0, out[i + 1] = counts[0] + ... + counts[i]: one workgroup, blocks of 256 with a
+// running carry.
+__global__ __launch_bounds__(256) void k_scan_counts(const int64_t* __restrict__ counts, int64_t n,
+                                                     int64_t* __restrict__ out) {
+  __shared__ int64_t buf[256];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) {
+    carry = 0;
+    out[0] = 0;
+  }
+  __syncthreads();
+  for (int64_t b = 0; b < n; b += 256) {
+    const int64_t i = b + threadIdx.x;
+    int64_t v = i < n ? counts[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int64_t t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n) out[i + 1] = carry + buf[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 255) carry += buf[255];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void k_compact_matches(
+    const uint8_t* __restrict__ mask, const int32_t* __restrict__ i1,
+    const int64_t* __restrict__ row_off, const int64_t* __restrict__ out_off,
+    const double* __restrict__ kp_q, int64_t n_q, const double* __restrict__ kp_rows,
+    int32_t* __restrict__ match_q, int32_t* __restrict__ match_im, double* __restrict__ pts) {
+  const int64_t c = blockIdx.x;
+  const int64_t r0 = row_off[c], r1 = row_off[c + 1];
+  int64_t pos = out_off[c];
+  const int lane = threadIdx.x;
+  for (int64_t j0 = r0; j0 < r1; j0 += 64) {
+    const int64_t j = j0 + lane;
+    const bool m = j < r1 && mask[j] != 0;
+    const unsigned long long b = __ballot(m);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (m) {
+      const int64_t o = pos + before;
+      int32_t q = i1[j];
+      match_q[o] = q;
+      match_im[o] = (int32_t)(j - r0);
+      if (pts) {
+        if (q < 0) q = 0;
+        if (q >= n_q) q = (int32_t)(n_q - 1);
+        pts[o * 4 + 0] = kp_q[(int64_t)q * 2 + 0];
+        pts[o * 4 + 1] = kp_q[(int64_t)q * 2 + 1];
+        pts[o * 4 + 2] = kp_rows[j * 2 + 0];
+        pts[o * 4 + 3] = kp_rows[j * 2 + 1];
+      }
+    }
+    pos += __popcll(b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// homography helpers (every lane of a wave computes the same model redundantly, in registers)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double tri(double ax, double ay, double bx, double by, double cx,
+                                      double cy) {
+  return (bx - ax) * (cy - ay) - (cx - ax) * (by - ay);
+}
+
+// columns c_i * (x_i, y_i, 1) of the map from the projective basis to four points
+__device__ __forceinline__ void basis_map(const double* p /*x0,y0,..,x3,y3*/, double* A) {
+  const double c0 = tri(p[6], p[7], p[2], p[3], p[4], p[5]);
+  const double c1 = tri(p[0], p[1], p[6], p[7], p[4], p[5]);
+  const double c2 = tri(p[0], p[1], p[2], p[3], p[6], p[7]);
+  A[0] = c0 * p[0]; A[1] = c1 * p[2]; A[2] = c2 * p[4];
+  A[3] = c0 * p[1]; A[4] = c1 * p[3]; A[5] = c2 * p[5];
+  A[6] = c0;        A[7] = c1;        A[8] = c2;
+}
+
+// The homography that maps four source points onto four destination points, scaled to H[8] = 1.
+// Degenerate samples (three collinear points) give non-finite entries; every comparison against
+// them is false, so such a model simply has no inliers.
+__device__ __forceinline__ void homography4(const double* src, const double* dst, double* H) {
+  double A[9], B[9], J[9];
+  basis_map(src, A);
+  basis_map(dst, B);
+  J[0] = A[4] * A[8] - A[5] * A[7];
+  J[1] = A[2] * A[7] - A[1] * A[8];
+  J[2] = A[1] * A[5] - A[2] * A[4];
+  J[3] = A[5] * A[6] - A[3] * A[8];
+  J[4] = A[0] * A[8] - A[2] * A[6];
+  J[5] = A[2] * A[3] - A[0] * A[5];
+  J[6] = A[3] * A[7] - A[4] * A[6];
+  J[7] = A[1] * A[6] - A[0] * A[7];
+  J[8] = A[0] * A[4] - A[1] * A[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      H[r * 3 + c] = B[r * 3] * J[c] + B[r * 3 + 1] * J[3 + c] + B[r * 3 + 2] * J[6 + c];
+  const double inv = 1.0 / H[8];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) H[e] *= inv;
+}
+
+// HomographyModel.get_error (model/robust_matching.py:273-281) for one pair
+__device__ __forceinline__ double reproj_error(const double* H, double x, double y, double u,
+                                               double v) {
+  const double w = H[6] * x + H[7] * y + H[8];
+  const double den = w + kProjEps;
+  const double tx = (H[0] * x + H[1] * y + H[2]) / den;
+  const double ty = (H[3] * x + H[4] * y + H[5]) / den;
+  const double tz = w / den;
+  const double dx = u - tx, dy = v - ty, dz = 1.0 - tz;
+  return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// four distinct pair indices of iteration `it` of candidate `cand`: the caller's (clamped into
+// range), or drawn without replacement from a counter-based generator
+__device__ __forceinline__ void sample4(const int32_t* __restrict__ samples, int64_t cand, int it,
+                                        int n_iter, int n, uint64_t seed, int* s) {
+  if (samples) {
+    const int32_t* sp = samples + ((int64_t)cand * n_iter + it) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int v = sp[k];
+      v = v < 0 ? 0 : v;
+      s[k] = v >= n ? n - 1 : v;
+    }
+    return;
+  }
+  uint64_t state = mix64(seed ^ mix64((uint64_t)cand * 0x100000001b3ull + (uint64_t)it));
+  int sorted[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    state = mix64(state);
+    int v = (int)(state % (uint64_t)(n - k));
+    // skip over the indices already taken (kept sorted), which makes the draw uniform over the rest
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < k && v >= sorted[t]) ++v;
+    s[k] = v;
+    int ins = v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int lo = ins < sorted[t] ? ins : sorted[t];
+      const int hi = ins < sorted[t] ? sorted[t] : ins;
+      sorted[t] = lo;
+      ins = hi;
+    }
+  }
+}
+
+__device__ __forceinline__ void load_sample(const double* __restrict__ pts, const int* s,
+                                            double* src, double* dst) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double* p = pts + (int64_t)s[k] * 4;
+    src[2 * k] = p[0];
+    src[2 * k + 1] = p[1];
+    dst[2 * k] = p[2];
+    dst[2 * k + 1] = p[3];
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ransac_score: n_inl[cand][it] = pairs outside the sample whose reprojection error is < th
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ransac_score(
+    const double* __restrict__ pts_all, const int64_t* __restrict__ off, int n_iter,
+    const int32_t* __restrict__ samples, uint64_t seed, double th, int32_t* __restrict__ n_inl) {
+  const int64_t cand = blockIdx.x;
+  const int64_t p0 = off[cand];
+  const int n = (int)(off[cand + 1] - p0);
+  const double* pts = pts_all + p0 * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int it_end = min(n_iter, ((int)blockIdx.y + 1) * kItersPerWg);
+  for (int it = (int)blockIdx.y * kItersPerWg + wave; it < it_end; it += 4) {
+    int cnt = 0;
+    if (n >= 4) {
+      int s[4];
+      sample4(samples, cand, it, n_iter, n, seed, s);
+      double src[8], dst[8], H[9];
+      load_sample(pts, s, src, dst);
+      homography4(src, dst, H);
+      for (int j = lane; j < n; j += 64) {
+        const double* p = pts + (int64_t)j * 4;
+        const double e = reproj_error(H, p[0], p[1], p[2], p[3]);
+        const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
+        cnt += (!in_sample && e < th) ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) n_inl[cand * n_iter + it] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ransac_refit
+// ---------------------------------------------------------------------------------------------
+// In-register Cholesky factor of the packed symmetric 9x9 matrix a (row-major lower triangle,
+// a[r*(r+1)/2 + c], c <= r), in place.
+__device__ __forceinline__ void cholesky9(double* a) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double d = a[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= a[j * (j + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
+    d = sqrt(d);
+    a[j * (j + 1) / 2 + j] = d;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = j + 1; i < 9; ++i) {
+      double s = a[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= a[i * (i + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
+      a[i * (i + 1) / 2 + j] = s * inv;
+    }
+  }
+}
+
+// v <- (L L^T)^-1 v
+__device__ __forceinline__ void chol_solve9(const double* L, double* v) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    double s = v[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i * (i + 1) / 2 + k] * v[k];
+    v[i] = s / L[i * (i + 1) / 2 + i];
+  }
+#pragma unroll
+  for (int i = 8; i >= 0; --i) {
+    double s = v[i];
+#pragma unroll
+    for (int k = i + 1; k < 9; ++k) s -= L[k * (k + 1) / 2 + i] * v[k];
+    v[i] = s / L[i * (i + 1) / 2 + i];
+  }
+}
+
+__global__ __launch_bounds__(64) void k_ransac_refit(
+    const double* __restrict__ pts_all, const int64_t* __restrict__ off, int n_iter,
+    const int32_t* __restrict__ samples, uint64_t seed, double th, int min_inliers,
+    int accept_mean_err, const int32_t* __restrict__ n_inl, double* __restrict__ H_out,
+    int32_t* __restrict__ n_inliers, double* __restrict__ best_err, int32_t* __restrict__ best_it,
+    uint8_t* __restrict__ mask_all) {
+  const int64_t cand = blockIdx.x;
+  const int64_t p0 = off[cand];
+  const int n = (int)(off[cand + 1] - p0);
+  const double* pts = pts_all + p0 * 4;
+  uint8_t* mask = mask_all + p0;
+  const int lane = threadIdx.x;
+
+  bool ok = n >= 4 && n_iter > 0;
+  // first iteration with the largest count
+  int bc = -1, bi = 0x7fffffff;
+  for (int it = lane; it < n_iter; it += 64) {
+    const int c = n_inl[cand * n_iter + it];
+    if (c > bc) {
+      bc = c;
+      bi = it;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const int oc = __shfl_xor(bc, o), oi = __shfl_xor(bi, o);
+    if (oc > bc || (oc == bc && oi < bi)) {
+      bc = oc;
+      bi = oi;
+    }
+  }
+
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double err_mean = __builtin_inf();
+  int count = 0;
+  if (ok) {
+    int s[4];
+    sample4(samples, cand, bi, n_iter, n, seed, s);
+    double src[8], dst[8], H4[9];
+    load_sample(pts, s, src, dst);
+    homography4(src, dst, H4);
+    // inlier flags (the sample itself always belongs to the consensus set) and centroids
+    double sx = 0, sy = 0, su = 0, sv = 0, sc = 0;
+    for (int j = lane; j < n; j += 64) {
+      const double* p = pts + (int64_t)j * 4;
+      const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
+      const bool in = in_sample || reproj_error(H4, p[0], p[1], p[2], p[3]) < th;
+      mask[j] = in ? 1 : 0;
+      const double f = in ? 1.0 : 0.0;
+      sx += f * p[0]; sy += f * p[1]; su += f * p[2]; sv += f * p[3]; sc += f;
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); su = wave_sum(su); sv = wave_sum(sv); sc = wave_sum(sc);
+    count = (int)sc;
+    const double cMx = sx / sc, cMy = sy / sc, cmx = su / sc, cmy = sv / sc;
+    double ax = 0, ay = 0, au = 0, av = 0;
+    for (int j = lane; j < n; j += 64) {
+      const double* p = pts + (int64_t)j * 4;
+      const double f = mask[j] ? 1.0 : 0.0;
+      ax += f * fabs(p[0] - cMx); ay += f * fabs(p[1] - cMy);
+      au += f * fabs(p[2] - cmx); av += f * fabs(p[3] - cmy);
+    }
+    ax = wave_sum(ax); ay = wave_sum(ay); au = wave_sum(au); av = wave_sum(av);
+    const double eps = 2.220446049250313e-16;
+    if (ax < eps || ay < eps || au < eps || av < eps) ok = false;
+    if (ok) {
+      const double sMx = sc / ax, sMy = sc / ay, smx = sc / au, smy = sc / av;
+      // the four 3x3 moment blocks of L^T L: S0 = sum a a^T, Sx = sum x a a^T, Sy = sum y a a^T,
+      // Sr = sum (x^2 + y^2) a a^T with a = (X, Y, 1) the normalised source point and (x, y) the
+      // normalised destination point; packed as (XX, XY, X1, YY, Y1, 11)
+      double S0[6] = {0, 0, 0, 0, 0, 0}, Sx[6] = {0, 0, 0, 0, 0, 0}, Sy[6] = {0, 0, 0, 0, 0, 0},
+             Sr[6] = {0, 0, 0, 0, 0, 0};
+      for (int j = lane; j < n; j += 64) {
+        const double* p = pts + (int64_t)j * 4;
+        const double f = mask[j] ? 1.0 : 0.0;
+        const double X = (p[0] - cMx) * sMx, Y = (p[1] - cMy) * sMy;
+        const double x = (p[2] - cmx) * smx, y = (p[3] - cmy) * smy;
+        const double m[6] = {f * X * X, f * X * Y, f * X, f * Y * Y, f * Y, f};
+        const double r2 = x * x + y * y;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          S0[e] += m[e];
+          Sx[e] += x * m[e];
+          Sy[e] += y * m[e];
+          Sr[e] += r2 * m[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        S0[e] = wave_sum(S0[e]);
+        Sx[e] = wave_sum(Sx[e]);
+        Sy[e] = wave_sum(Sy[e]);
+        Sr[e] = wave_sum(Sr[e]);
+      }
+      // packed lower triangle of L^T L + shift * I
+      const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+      double a[45];
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          const int br = r / 3, bc2 = c / 3, e = sym[r % 3][c % 3];
+          double v;
+          if (br == bc2) v = br == 2 ? Sr[e] : S0[e];
+          else if (br == 2) v = bc2 == 0 ? -Sx[e] : -Sy[e];
+          else v = 0.0;
+          a[r * (r + 1) / 2 + c] = v;
+        }
+      const double trace = 2.0 * (S0[0] + S0[3] + S0[5]) + Sr[0] + Sr[3] + Sr[5];
+      const double shift = trace * 1e-12;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) a[r * (r + 1) / 2 + r] += shift;
+      cholesky9(a);
+      // inverse iteration towards the eigenvector of the smallest eigenvalue
+      double v[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll 1
+      for (int rep = 0; rep < 8; ++rep) {
+        chol_solve9(a, v);
+        double nrm = 0;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) nrm += v[e] * v[e];
+        nrm = 1.0 / sqrt(nrm);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) v[e] *= nrm;
+      }
+      // H = invHnorm * H0 * Hnorm2, scaled to H[8] = 1
+      double T[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        T[c] = v[c] / smx + cmx * v[6 + c];
+        T[3 + c] = v[3 + c] / smy + cmy * v[6 + c];
+        T[6 + c] = v[6 + c];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        H[r * 3 + 0] = T[r * 3 + 0] * sMx;
+        H[r * 3 + 1] = T[r * 3 + 1] * sMy;
+        H[r * 3 + 2] = T[r * 3 + 2] - T[r * 3 + 0] * cMx * sMx - T[r * 3 + 1] * cMy * sMy;
+      }
+      const double inv = 1.0 / H[8];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) H[e] *= inv;
+      double es = 0;
+      for (int j = lane; j < n; j += 64) {
+        const double* p = pts + (int64_t)j * 4;
+        const double e = reproj_error(H, p[0], p[1], p[2], p[3]);
+        es += mask[j] ? e : 0.0;
+      }
+      err_mean = wave_sum(es) / sc;
+    }
+  }
+  bool accept = ok && count >= min_inliers;
+  if (accept_mean_err) accept = accept && err_mean <= th;
+  if (!accept)
+    for (int j = lane; j < n; j += 64) mask[j] = 0;
+  if (lane < 9) H_out[cand * 9 + lane] = accept ? H[lane] : 0.0;
+  if (lane == 0) {
+    n_inliers[cand] = accept ? count : 0;
+    best_err[cand] = err_mean;
+    if (best_it) best_it[cand] = ok ? bi : -1;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_compact_matches(const uint8_t* mask, const int32_t* i1, const int64_t* row_off,
+                                  int64_t n_cand, const double* kp_q, int64_t n_q,
+                                  const double* kp_rows, int64_t* counts_ws, int64_t* out_off,
+                                  int32_t* match_q, int32_t* match_im, double* pts, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_matches, dim3((unsigned)n_cand), dim3(64), 0, s, mask, row_off,
+                     counts_ws);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, s, counts_ws, n_cand, out_off);
+  hipLaunchKernelGGL(k_compact_matches, dim3((unsigned)n_cand), dim3(64), 0, s, mask, i1, row_off,
+                     out_off, kp_q, n_q, kp_rows, match_q, match_im, pts);
+  return hipGetLastError();
+}
+
+hipError_t launch_ransac(const double* pts, const int64_t* off, int64_t n_cand, int n_iter,
+                         const int32_t* samples, uint64_t seed, double th, int min_inliers,
+                         int accept_mean_err, int32_t* n_inl_ws, double* H, int32_t* n_inliers,
+                         double* best_err, int32_t* best_it, uint8_t* mask, hipStream_t s) {
+  if (n_iter > 0) {
+    const dim3 grid((unsigned)n_cand, (unsigned)((n_iter + kItersPerWg - 1) / kItersPerWg));
+    hipLaunchKernelGGL(k_ransac_score, grid, dim3(256), 0, s, pts, off, n_iter, samples, seed, th,
+                       n_inl_ws);
+  }
+  hipLaunchKernelGGL(k_ransac_refit, dim3((unsigned)n_cand), dim3(64), 0, s, pts, off, n_iter,
+                     samples, seed, th, min_inliers, accept_mean_err, n_inl_ws, H, n_inliers,
+                     best_err, best_it, mask);
+  return hipGetLastError();
+}
+
+}  // namespace ic

@@ -296,6 +296,74 @@ def knn_rows(x, c, k, metric="euclidean"):
     return dist, idx
 
 
+def compact_matches(mask, i1, row_offsets, kp_query=None, kp_rows=None):
+    """Per-candidate match lists from the ratio-test mask of one batched search.
+
+    mask uint8 [rows], i1 int32 [rows], row_offsets int64 [n_cand + 1] (device).  Returns
+    (out_offsets int64 [n_cand + 1], match_q int32 [rows], match_im int32 [rows], pts): candidate
+    c's matches are entries out_offsets[c]:out_offsets[c+1]; pts float64 [rows, 4] holds
+    (x_q, y_q, x_im, y_im) per match when both keypoint arrays (float64 [n, 2]) are given."""
+    if mask.dtype != torch.uint8 or i1.dtype != torch.int32 or row_offsets.dtype != torch.int64:
+        raise ValueError("mask must be uint8, i1 int32 and row_offsets int64")
+    rows = mask.shape[0]
+    if i1.shape[0] != rows:
+        raise ValueError("mask and i1 must have one entry per search row")
+    dev = _dev_index(mask)
+    n_cand = row_offsets.shape[0] - 1
+    out_off = torch.empty(n_cand + 1, dtype=torch.int64, device=mask.device)
+    match_q = torch.empty(rows, dtype=torch.int32, device=mask.device)
+    match_im = torch.empty(rows, dtype=torch.int32, device=mask.device)
+    pts = None
+    n_q = 0
+    if kp_query is not None or kp_rows is not None:
+        if kp_query is None or kp_rows is None:
+            raise ValueError("give both kp_query and kp_rows, or neither")
+        for t, name in ((kp_query, "kp_query"), (kp_rows, "kp_rows")):
+            if t.dtype != torch.float64 or t.dim() != 2 or t.shape[1] != 2 or not t.is_contiguous():
+                raise ValueError("%s must be contiguous float64 [n, 2]" % name)
+        if kp_rows.shape[0] != rows or kp_query.shape[0] < 1:
+            raise ValueError("kp_rows needs one keypoint per search row and kp_query at least one")
+        n_q = kp_query.shape[0]
+        pts = torch.empty((rows, 4), dtype=torch.float64, device=mask.device)
+    rc = _lib.load().ic_compact_matches(
+        _lib.handle(dev), _ptr(mask.contiguous()), _ptr(i1.contiguous()),
+        _ptr(row_offsets.contiguous()), n_cand, _ptr(kp_query), n_q, _ptr(kp_rows), _ptr(out_off),
+        _ptr(match_q), _ptr(match_im), _ptr(pts), _stream_ptr(dev))
+    _lib.check(rc, "ic_compact_matches")
+    return out_off, match_q, match_im, pts
+
+
+def ransac_homography(pts, offsets, n_iter, th, samples=None, seed=0, min_inliers=10,
+                      accept_mean_err=True):
+    """Homography RANSAC for every candidate's matched pairs at once.
+
+    pts float64 [total, 4], offsets int64 [n_cand + 1] (device), samples int32
+    [n_cand, n_iter, 4] or None.  Returns (H float64 [n_cand, 3, 3], n_inliers int32 [n_cand],
+    best_err float64 [n_cand], best_iter int32 [n_cand], inlier_mask uint8 [total])."""
+    if pts.dtype != torch.float64 or pts.dim() != 2 or pts.shape[1] != 4 or not pts.is_contiguous():
+        raise ValueError("pts must be contiguous float64 [total, 4]")
+    if offsets.dtype != torch.int64:
+        raise ValueError("offsets must be int64")
+    dev = _dev_index(pts)
+    n_cand = offsets.shape[0] - 1
+    n_iter = int(n_iter)
+    if samples is not None:
+        if samples.dtype != torch.int32 or tuple(samples.shape) != (n_cand, n_iter, 4):
+            raise ValueError("samples must be int32 [n_cand, n_iter, 4]")
+        samples = samples.contiguous()
+    H = torch.empty((n_cand, 3, 3), dtype=torch.float64, device=pts.device)
+    n_inl = torch.empty(n_cand, dtype=torch.int32, device=pts.device)
+    err = torch.empty(n_cand, dtype=torch.float64, device=pts.device)
+    best_it = torch.empty(n_cand, dtype=torch.int32, device=pts.device)
+    mask = torch.zeros(pts.shape[0], dtype=torch.uint8, device=pts.device)
+    rc = _lib.load().ic_ransac_homography(
+        _lib.handle(dev), _ptr(pts), _ptr(offsets.contiguous()), n_cand, n_iter, _ptr(samples),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, float(th), int(min_inliers), 1 if accept_mean_err else 0,
+        _ptr(H), _ptr(n_inl), _ptr(err), _ptr(best_it), _ptr(mask), _stream_ptr(dev))
+    _lib.check(rc, "ic_ransac_homography")
+    return H, n_inl, err, best_it, mask
+
+
 def profile_begin(device_index):
     """Start timing the distance kernel of every following assign call on this device."""
     _lib.check(_lib.load().ic_profile_begin(_lib.handle(device_index)), "ic_profile_begin")

@@ -1,15 +1,24 @@
-"""`RobustMatcher` with the reference's interface; its descriptor-matching stage runs on the device.
+"""`RobustMatcher` with the reference's interface; matching and verification run on the device.
 
-Mirrors model/robust_matching.py:16-96 and :177-194.  In `match(query, image_list)` the reference
+Mirrors model/robust_matching.py:16-96 and :156-226.  In `match(query, image_list)` the reference
 fits a brute-force 2-NN index on the QUERY descriptors and, for every candidate image with more
-than `min_points` descriptors, searches the candidate's descriptors in it and keeps row `idx`
-when `dist[idx, 0] < dist[idx, 1] * knn_thresh` (:73-84, a Python loop over rows).  Here the
-descriptors of all candidates are concatenated, one device call returns both neighbours and the
-ratio mask for every row, and the per-candidate match lists are cut out of that.
+than `min_points` descriptors, searches the candidate's descriptors in it, keeps row `idx` when
+`dist[idx, 0] < dist[idx, 1] * knn_thresh` (:73-84, a Python loop over rows), gathers the matched
+keypoints and scores them with a homography RANSAC (:85-95, :156-226).  Here the descriptors of
+all candidates are concatenated and the whole query is four device calls: both neighbours and
+the ratio mask for every row, the per-candidate match lists with their keypoint pairs, and one
+batched RANSAC over all candidates.
 
-The geometric verification that follows (`_score_matches` -> homography RANSAC through
-cv2.findHomography, :156-226) is not part of the accelerated path: pass `homography_fn`, a
-callable `(q_points [m,2], im_points [m,2]) -> (retval, mask)`, or have cv2 importable.
+RANSAC variants (`ransac_algorithm`): any value other than cv2.RANSAC (8) selects the reference's
+own `ransac()` (:291-365): int(log(1-prob)/log(1-inlier_r^4)) iterations capped by
+`ransac_max_iter`, at least MIN_INLIERS_TH = 10 inliers and a mean reprojection error within
+`ransac_th`.  The default 8 stands for cv2.findHomography(..., cv2.RANSAC, ransac_th); OpenCV is
+not used here, the same device kernels run with OpenCV's published defaults instead (2000
+iterations, at least 4 inliers, no mean-error rule).  Samples come from a counter-based generator
+on the device, seeded per call from numpy's global generator (so `np.random.seed` makes a run
+repeatable, as it does for the reference's `np.random.shuffle`).  A `homography_fn`
+callable `(q_points [m,2], im_points [m,2]) -> (H, mask)` replaces the device RANSAC per
+candidate when given.
 """
 from logging import getLogger
 
@@ -22,6 +31,16 @@ __all__ = ["RobustMatcher"]
 logger = getLogger("affine.detection.model.robust_matching")
 
 CV_RANSAC = 8  # value of cv2.RANSAC, the reference's default `ransac_algorithm`
+MIN_INLIERS_TH = 10        # model/robust_matching.py:13
+CV_RANSAC_MAX_ITERS = 2000  # OpenCV's default maxIters of findHomography
+
+
+def ransac_num_iterations(max_iter, p, w, min_model_points=4):
+    """Iteration count of the reference's ransac() (model/robust_matching.py:320-322)."""
+    num = np.log(1 - p) / np.log(1 - (w ** min_model_points))
+    if max_iter > 0:
+        num = np.min([max_iter, int(num)])
+    return int(num)
 
 
 class RobustMatcher(object):
@@ -79,6 +98,55 @@ class RobustMatcher(object):
             out[n] = (i1[lo:hi][m].astype(np.int64), np.nonzero(m)[0].astype(np.int64))
         return out
 
+    def _ransac_params(self):
+        if self.ransac_algorithm == CV_RANSAC:
+            return CV_RANSAC_MAX_ITERS, 4, False
+        return (ransac_num_iterations(self.ransac_max_iter, self.ransac_prob, self.inlier_r),
+                MIN_INLIERS_TH, True)
+
+    def match_and_verify(self, query, image_list):
+        """The whole of `match` on the device.  Returns one dict per candidate with `n_matches`,
+        `inliers`, `matches_q`, `matches_im` (int64 rows) and `mask` (uint8 per match)."""
+        empty_i = np.empty(0, dtype=np.int64)
+        out = [dict(n_matches=0, inliers=0, matches_q=empty_i, matches_im=empty_i,
+                    mask=np.empty(0, dtype=np.uint8)) for _ in image_list]
+        use = [n for n, img in enumerate(image_list) if img.desc_rows > self.min_points]
+        if not use:
+            return out
+        if query.desc_rows < 2:
+            raise ValueError("Expected n_neighbors <= n_samples_fit, but n_neighbors = 2, "
+                             "n_samples_fit = %d" % query.desc_rows)
+        b = self._b()
+        rows = [0]
+        parts, kps = [], []
+        for n in use:
+            parts.append(np.asarray(image_list[n].descriptors, dtype=np.float32))
+            kps.append(np.asarray(image_list[n].keypoints, dtype=np.float64).reshape(-1, 2))
+            rows.append(rows[-1] + parts[-1].shape[0])
+        allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        i1, _d1, _i2, _d2, mask = b.assign_top2_np(allx, b.codebook(query.descriptors),
+                                                ratio=self.knn_thresh)
+        kp_rows = b.f64(np.ascontiguousarray(np.concatenate(kps)))
+        kp_q = b.f64(np.ascontiguousarray(np.asarray(query.keypoints, dtype=np.float64).reshape(-1, 2)))
+        out_off, match_q, match_im, pts = b.compact_matches(mask, i1, b.i64(rows), kp_q, kp_rows)
+        n_iter, min_inliers, mean_rule = self._ransac_params()
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        _H, n_inl, _err, _it, in_mask = b.ransac_homography(
+            pts, out_off, n_iter, float(self.ransac_th), None, seed, min_inliers, mean_rule)
+        out_off = out_off.cpu().numpy()
+        n_inl = n_inl.cpu().numpy()
+        total = int(out_off[-1])
+        match_q = match_q[:total].cpu().numpy().astype(np.int64)
+        match_im = match_im[:total].cpu().numpy().astype(np.int64)
+        in_mask = in_mask[:total].cpu().numpy()
+        for slot, n in enumerate(use):
+            lo, hi = int(out_off[slot]), int(out_off[slot + 1])
+            verified = (hi - lo) > self.min_matches
+            out[n] = dict(n_matches=hi - lo, inliers=int(n_inl[slot]) if verified else 0,
+                          matches_q=match_q[lo:hi], matches_im=match_im[lo:hi],
+                          mask=in_mask[lo:hi] if verified else np.empty(0, dtype=np.uint8))
+        return out
+
     def match(self, query, image_list):
         """Score of the query against each candidate: inliers / (number of matches or 1)."""
         if self.debug:
@@ -88,6 +156,21 @@ class RobustMatcher(object):
         num_feat_query = query.desc_rows
         if num_feat_query < self.min_points:
             return [0] * len(image_list)
+        if self.homography_fn is not None:
+            return self._match_with_callable(query, image_list)
+        img_scores = []
+        for img, res in zip(image_list, self.match_and_verify(query, image_list)):
+            if self.debug:
+                self.query_kpts.append(query.keypoints[res["matches_q"]])
+                self.imgs_kpts.append(img.keypoints[res["matches_im"]])
+                self.mask_list.append(res["mask"].reshape(-1, 1) if len(res["mask"]) else [])
+            img_scores.append(float(res["inliers"]) / (res["n_matches"] or 1))
+            logger.debug("%d inliers out of %d features in query %d features in model-img",
+                         res["inliers"], num_feat_query, img.desc_rows)
+        logger.debug("Scores obtained in robust matching %s", img_scores)
+        return img_scores
+
+    def _match_with_callable(self, query, image_list):
         matches = self.match_descriptors(query, image_list)
         img_scores = []
         for img, (matches_q, matches_im) in zip(image_list, matches):
@@ -101,9 +184,6 @@ class RobustMatcher(object):
                 self.imgs_kpts.append(img.keypoints[matches_im])
                 self.mask_list.append(mask)
             img_scores.append(float(inliers) / (len(matches_im) or 1))
-            logger.debug("%d inliers out of %d features in query %d features in model-img",
-                         inliers, num_feat_query, img.desc_rows)
-        logger.debug("Scores obtained in robust matching %s", img_scores)
         return img_scores
 
     def _score_matches(self, q_points, im_points):
@@ -117,16 +197,24 @@ class RobustMatcher(object):
         return num_inliers, mask
 
     def _robust_h_estimation(self, q_points, im_points, opt=CV_RANSAC):
+        """(homography or None, inlier mask [m, 1]) for one set of matched points."""
         if self.homography_fn is not None:
             return self.homography_fn(q_points, im_points)
+        b = self._b()
+        data = np.ascontiguousarray(np.append(np.asarray(q_points, dtype=np.float64).reshape(-1, 2),
+                                              np.asarray(im_points, dtype=np.float64).reshape(-1, 2),
+                                              axis=1))
+        saved, self.ransac_algorithm = self.ransac_algorithm, opt
         try:
-            import cv2
-        except ImportError:
-            raise NotImplementedError(
-                "homography estimation needs cv2 or a `homography_fn`; the device path covers the "
-                "descriptor matching stage (match_descriptors) only")
-        return cv2.findHomography(np.asarray(q_points), np.asarray(im_points), cv2.RANSAC,
-                                  self.ransac_th)
+            n_iter, min_inliers, mean_rule = self._ransac_params()
+        finally:
+            self.ransac_algorithm = saved
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+        H, n_inl, _err, _it, mask = b.ransac_homography(
+            b.f64(data), b.i64([0, data.shape[0]]), n_iter, float(self.ransac_th), None, seed,
+            min_inliers, mean_rule)
+        homography = H[0].cpu().numpy() if int(n_inl[0]) > 0 else None
+        return homography, mask.cpu().numpy().reshape(-1, 1)
 
     def predict(self, scores, labels):
         """Label of the best score if it reaches `accept_th`, else -1."""

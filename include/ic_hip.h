@@ -157,6 +157,37 @@ int ic_pairwise(void* handle, const float* x, int64_t m, const float* c, int64_t
 int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t n, int d,
                 int metric, int k, double* out_dist, int32_t* out_idx, void* stream);
 
+/* Ratio-test mask -> per-candidate match lists.  Replaces the Python loop at
+ * model/robust_matching.py:81-84 and the keypoint gathers at :85-86 for all candidate images of a
+ * query at once.  Candidate c owns search rows row_offsets[c] .. row_offsets[c+1]; its matches,
+ * in ascending row order, go to positions out_offsets[c] .. out_offsets[c+1] of the outputs.
+ *   mask [rows] uint8 and i1 [rows] int32 as written by ic_assign_top2, row_offsets [n_cand+1]
+ *   int64 (device), out_offsets [n_cand+1] int64, match_q / match_im [rows] int32 (query row,
+ *   row inside the candidate).  With kp_query [n_query][2] and kp_rows [rows][2] (float64 keypoint
+ *   coordinates) and pts [rows][4] non-NULL, pts receives (x_q, y_q, x_im, y_im) per match. */
+int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
+                       const int64_t* row_offsets, int64_t n_cand, const double* kp_query,
+                       int64_t n_query, const double* kp_rows, int64_t* out_offsets,
+                       int32_t* match_q, int32_t* match_im, double* pts, void* stream);
+
+/* Homography RANSAC over the matched pairs of every candidate image at once.  Replaces
+ * RobustMatcher._robust_h_estimation -> ransac(data, HomographyModel, 4, ...)
+ * (model/robust_matching.py:196-225, :291-365): per iteration a homography through four sampled
+ * pairs, inliers = other pairs with reprojection error (HomographyModel.get_error, :259-283)
+ * below th; the first iteration with the most inliers is refitted over sample + inliers by the
+ * direct linear transform and kept when it has at least min_inliers pairs and (accept_mean_err
+ * != 0) a mean reprojection error <= th, as :359-363 demands.
+ *   pts [total][4] float64 (x_src, y_src, x_dst, y_dst), offsets [n_cand+1] int64 (device),
+ *   samples [n_cand][n_iter][4] int32 pair indices inside the candidate, or NULL to draw them
+ *   from a counter-based generator seeded with `seed`;
+ *   H [n_cand][9] float64 (zeros when rejected), n_inliers [n_cand] int32 (0 when rejected),
+ *   best_err [n_cand] float64, best_iter [n_cand] int32 or NULL, inlier_mask [total] uint8.
+ * Candidates with fewer than four pairs are rejected. */
+int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets, int64_t n_cand,
+                         int n_iter, const int32_t* samples, uint64_t seed, double th,
+                         int min_inliers, int accept_mean_err, double* H, int32_t* n_inliers,
+                         double* best_err, int32_t* best_iter, uint8_t* inlier_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,64 @@ class CheckerBackend(object):
         self.calls.append(("knn_rows", tuple(x.shape), tuple(c.shape), metric, k))
         d, i = oracle.kneighbors_metric(c.numpy(), x.numpy(), k, metric)
         return torch.from_numpy(d), torch.from_numpy(i.astype(np.int32))
+
+    def u8(self, a):
+        return torch.as_tensor(np.asarray(a), dtype=torch.uint8)
+
+    def compact_matches(self, mask, i1, row_offsets, kp_query=None, kp_rows=None):
+        m = mask.numpy().astype(bool)
+        off = row_offsets.numpy()
+        rows = m.shape[0]
+        out_off = np.zeros(len(off), dtype=np.int64)
+        mq = np.zeros(rows, dtype=np.int32)
+        mi = np.zeros(rows, dtype=np.int32)
+        pts = np.zeros((rows, 4)) if kp_query is not None else None
+        pos = 0
+        for c in range(len(off) - 1):
+            local = np.nonzero(m[off[c]:off[c + 1]])[0]
+            n = len(local)
+            mq[pos:pos + n] = i1.numpy()[off[c] + local]
+            mi[pos:pos + n] = local
+            if pts is not None:
+                pts[pos:pos + n, :2] = kp_query.numpy()[mq[pos:pos + n]]
+                pts[pos:pos + n, 2:] = kp_rows.numpy()[off[c] + local]
+            pos += n
+            out_off[c + 1] = pos
+        return (torch.from_numpy(out_off), torch.from_numpy(mq), torch.from_numpy(mi),
+                None if pts is None else torch.from_numpy(pts))
+
+    def ransac_homography(self, pts, offsets, n_iter, th, samples=None, seed=0, min_inliers=10,
+                          accept_mean_err=True):
+        from oracle import ransac_ref
+        off = offsets.numpy()
+        n_cand = len(off) - 1
+        H = np.zeros((n_cand, 3, 3))
+        n_inl = np.zeros(n_cand, dtype=np.int32)
+        err = np.full(n_cand, np.inf)
+        best_it = np.full(n_cand, -1, dtype=np.int32)
+        mask = np.zeros(pts.shape[0], dtype=np.uint8)
+        for c in range(n_cand):
+            data = pts.numpy()[off[c]:off[c + 1]]
+            n = data.shape[0]
+            if n < 4 or n_iter < 1:
+                continue
+            if samples is not None:
+                parts = []
+                for it in range(n_iter):
+                    cand = samples.numpy()[c, it].astype(np.int64)
+                    parts.append((cand, np.setdiff1d(np.arange(n), cand)))
+            else:
+                rng = np.random.RandomState((int(seed) + 7919 * c) % (2 ** 32))
+                parts = [ransac_ref.random_partition(4, n, rng) for _ in range(n_iter)]
+            info = {}
+            fit, m, e = ransac_ref.ransac(data, ransac_ref.HomographyModel, 4, 0, th,
+                                          partitions=parts, num_it=n_iter, min_inliers=min_inliers,
+                                          accept_mean_err=accept_mean_err, info=info)
+            err[c] = e
+            best_it[c] = info["best_it"]
+            if fit is not None:
+                H[c] = fit
+                n_inl[c] = int(m.sum())
+                mask[off[c]:off[c + 1]] = m
+        return (torch.from_numpy(H), torch.from_numpy(n_inl), torch.from_numpy(err),
+                torch.from_numpy(best_it), torch.from_numpy(mask))

@@ -299,6 +299,50 @@ def test_robust_matcher_descriptor_stage(backend):
         rm.predict([0.1], ["a", "b"])
 
 
+def test_robust_matcher_match_end_to_end(backend):
+    # a query logo, three candidates that really contain it (warped, partly occluded) and three
+    # that do not: matching, compaction and RANSAC all on the backend
+    from image_classification_amd.synthetic import sift_like
+    rng = np.random.default_rng(77)
+    nq = 400
+    q_desc = sift_like(nq, seed=70)
+    q_kp = rng.random((nq, 2)) * 500
+    query = ImageDesc([tuple(p) for p in q_kp], q_desc)
+    images, truth = [], []
+    for n, present in [(300, True), (250, False), (500, True), (200, False), (3, True), (350, True)]:
+        desc = sift_like(n, seed=100 + n)
+        kp = rng.random((n, 2)) * 500
+        if present:
+            H = np.array([[1.1, 0.05, 20.0], [-0.04, 0.95, 10.0], [5e-5, 2e-5, 1.0]])
+            m = min(n, 120)
+            src = rng.choice(nq, size=m, replace=False)
+            desc[:m] = q_desc[src] + rng.normal(0, 2.0, size=(m, 128)).astype(np.float32)
+            t = np.c_[q_kp[src], np.ones(m)].dot(H.T)
+            kp[:m] = t[:, :2] / t[:, 2:] + rng.normal(0, 0.3, size=(m, 2))
+            kp[:m // 6] = rng.random((m // 6, 2)) * 500      # some wrong geometry among the matches
+        images.append(ImageDesc([tuple(p) for p in kp], desc))
+        truth.append(present and n > 10)
+    for algo in (8, 0):                                       # OpenCV-style rule / the reference's own
+        np.random.seed(3)
+        rm = RobustMatcher(min_points=10, min_matches=8, ransac_th=3, accept_th=0.3,
+                           ransac_algorithm=algo, ransac_max_iter=100, debug=True, backend=backend)
+        scores = rm.match(query, images)
+        assert len(scores) == len(images)
+        for s, t in zip(scores, truth):
+            assert (s > 0.6) if t else (s == 0)
+        assert rm.predict(scores, list("abcdef")) in ("a", "c", "f")
+        assert len(rm.mask_list) == len(images) and len(rm.query_kpts[0]) == len(rm.imgs_kpts[0])
+        # the matched keypoints really are the planted correspondences
+        res = rm.match_and_verify(query, images)
+        assert res[0]["n_matches"] >= 100 and res[1]["inliers"] == 0 and res[4]["n_matches"] == 0
+        ref_q, ref_im = oracle.robust_match_descriptors(q_desc, [images[0].descriptors], 10, 0.8)[0]
+        assert np.array_equal(res[0]["matches_im"], ref_im) and np.array_equal(res[0]["matches_q"], ref_q)
+    # one candidate through the per-call entry the reference exposes
+    h, mask = rm._robust_h_estimation(query.keypoints[res[0]["matches_q"]],
+                                      images[0].keypoints[res[0]["matches_im"]], opt=0)
+    assert h is not None and mask.shape == (res[0]["n_matches"], 1) and mask.sum() >= 80
+
+
 # ---- kmeans2 -------------------------------------------------------------------------------------
 def _cb_err(got, ref):
     return float(np.max(np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)))
