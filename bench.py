@@ -16,6 +16,9 @@ sizing cases, run by hand for DESIGN.md, not the line the driver records):
           all-gather + merge of the per-rank records
   kmeans  config 4: one Lloyd iteration over 10M/8 rows, K = 65536, all-reduce of sums/counts
   video   config 5: 2000 frames x 2k descriptors per GPU, K = 10k, power-L2 histograms
+  logo    config 3 in the reference's own direction: the 2M descriptors of 2000 logo images are
+          searched in the 4k-descriptor index of the query (top-2 + ratio test), matches are
+          compacted per logo and verified by the batched homography RANSAC
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA distance /
 top-2 kernel): algorithmic FLOPs per launch = 2 * N * K * D, divided by its average duration
@@ -50,6 +53,10 @@ WORKLOADS = {
     "kmeans": dict(rows=1_250_000, k=65_536,
                    name="BASELINE config 4 (per-GPU share): one Lloyd iteration, 1.25M rows x 65536 "
                         "centroids x 128-d, all-reduce of sums/counts"),
+    "logo": dict(rows=2_000_000, k=4000, images=2000,
+                 name="BASELINE config 3 (reference direction): 2000 logo images x 1000 descriptors "
+                      "searched in a 4k-descriptor query index, top-2 + ratio test, per-logo match "
+                      "compaction, homography RANSAC (46 iterations, threshold 3 px)"),
     "knn": dict(rows=4000, k=2_000_000,
                 name="BASELINE config 3: 4k query descriptors vs 2M-descriptor index (split over "
                      "ranks), top-2 + ratio test, all-gather + merge"),
@@ -74,6 +81,35 @@ def cpu_baseline(x_sample, codebook, per_image, norm):
             "kind": "port",
             "sample": "%d rows of the workload (same codebook; float64 numpy GEMM + argmin + "
                       "np.histogram), %.1f s" % (x_sample.shape[0], dt)}, code
+
+
+def cpu_baseline_logo(x, kp_rows, q, kp_q, per, n_logos, n_iter, gpu_inliers, gpu_off):
+    """Oracle restatement of the reference's per-logo loop (2-NN + ratio test + its own ransac())
+    on the first `n_logos` logo images; reports rows/s and how often accept/reject agrees."""
+    import oracle
+    from oracle import ransac_ref
+    rows = n_logos * per
+    xs = x[:rows].cpu().numpy()
+    kps = kp_rows[:rows].cpu().numpy()
+    qn, kq = q.cpu().numpy(), kp_q.cpu().numpy()
+    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    rng = np.random.RandomState(1)
+    t0 = time.perf_counter()
+    accepted = []
+    for i in range(n_logos):
+        mq, mi = oracle.robust_match_descriptors(qn, [xs[i * per:(i + 1) * per]], 10, 0.8)[0]
+        ok = False
+        if len(mi) > 8:
+            data = np.append(kq[mq], kps[i * per:(i + 1) * per][mi], axis=1)
+            fit, mask, _ = ransac_ref.ransac(data, ransac_ref.HomographyModel, 4, 100, 3.0, rng=rng)
+            ok = fit is not None
+        accepted.append(ok)
+    dt = time.perf_counter() - t0
+    gpu_ok = gpu_inliers[:n_logos].cpu().numpy() > 0
+    return {"value": rows / dt, "unit": "assignments/s", "cores": cores, "kind": "port",
+            "sample": "%d logo images (%d rows): float64 numpy 2-NN + ratio test + the reference's "
+                      "ransac() restated, %.1f s" % (n_logos, rows, dt),
+            "agreement_with_gpu": float(np.mean(gpu_ok == np.asarray(accepted)))}
 
 
 def measured_traffic(workload):
@@ -151,6 +187,36 @@ def main():
             c, labels, _ = D.lloyd(x, state["c"], 1, backend, allreduce=allreduce)
             state["c"] = c
             return labels, c
+    elif args.workload == "logo":
+        n_img, per = w["images"], n_rows // w["images"]
+        g = torch.Generator(device=dev)
+        g.manual_seed(11 + rank)
+        q = sift_like_device(k_words, DIM, n_modes=4096, seed=5, device=dev)
+        kp_q = torch.rand((k_words, 2), dtype=torch.float64, device=dev, generator=g) * 500
+        x = sift_like_device(n_rows, DIM, n_modes=4096, seed=6 + 1000 * rank, device=dev)
+        kp_rows = torch.rand((n_rows, 2), dtype=torch.float64, device=dev, generator=g) * 500
+        # every second logo really contains the query: 60 of its rows are noisy copies of query
+        # descriptors whose keypoints follow one homography
+        planted = 60
+        hom = torch.tensor([[1.1, 0.05, 20.0], [-0.04, 0.95, 10.0], [5e-5, 2e-5, 1.0]],
+                           dtype=torch.float64, device=dev)
+        rows = (torch.arange(0, n_img, 2, device=dev)[:, None] * per
+                + torch.arange(planted, device=dev)[None, :]).reshape(-1)
+        src = torch.randint(0, k_words, (rows.numel(),), device=dev, generator=g)
+        x[rows] = q[src] + 2.0 * torch.randn((rows.numel(), DIM), device=dev, generator=g)
+        t = torch.cat([kp_q[src], torch.ones((rows.numel(), 1), dtype=torch.float64, device=dev)], 1) @ hom.T
+        kp_rows[rows] = t[:, :2] / t[:, 2:] + 0.3 * torch.randn((rows.numel(), 2), dtype=torch.float64,
+                                                                device=dev, generator=g)
+        row_off = torch.from_numpy(image_offsets(n_img, per)).to(dev)
+        cn = ops.row_sqnorm(q)
+        flops_per_launch = 2.0 * n_rows * k_words * DIM
+        n_iter = 46   # int(log(1 - 0.95) / log(1 - 0.5 ** 4)), the reference's defaults
+
+        def step():
+            i1, _d1, _i2, _d2, mask = ops.assign_top2(x, q, 0.8, cn)
+            out_off, mq, mi, pts = ops.compact_matches(mask, i1, row_off, kp_q, kp_rows)
+            res = ops.ransac_homography(pts, out_off, n_iter, 3.0, None, 1, 10, True)
+            return res[1], out_off
     else:  # knn: the index is split over ranks, the queries are replicated
         bounds = D.shard_bounds(k_words, world)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
@@ -208,6 +274,7 @@ def main():
                        "dim": DIM,
                        "parallelism": {"bow": "rows sharded, no collective",
                                        "video": "frames sharded, no collective",
+                                       "logo": "logo images sharded, no collective",
                                        "kmeans": "rows sharded, RCCL all-reduce of sums+counts per iteration",
                                        "knn": "index sharded, RCCL all-gather + top-2 merge"}[args.workload]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
@@ -223,6 +290,10 @@ def main():
             base, ref_code = cpu_baseline(x[:ns].cpu().numpy(), cb.cpu().numpy(), per_image, w["norm"])
             base["agreement_with_gpu"] = float(np.mean(ref_code == out_a[:ns].cpu().numpy()))
             out["cpu_baseline"] = base
+        if world == 1 and args.cpu_sample > 0 and args.workload == "logo":
+            out["cpu_baseline"] = cpu_baseline_logo(
+                x, kp_rows, q, kp_q, per, max(1, min(n_img, args.cpu_sample // per)), n_iter,
+                out_a, out_b)
         print(json.dumps(out), flush=True)
 
     if use_dist:
