@@ -241,6 +241,34 @@ __device__ __forceinline__ void tile_epilogue_skip(const f32x16 (&acc)[XT], Top2
   }
 }
 
+// The same, one level finer: inside a tile that some lane can improve, a register's candidate is
+// ranked only when some lane's value in THAT register beats its running second best (16 compares
+// and wave-uniform branches instead of 16 seven-instruction updates; a lane improves on about
+// 2/t of the tiles, so past the first few tiles most registers are skipped).
+template <int XT>
+__device__ __forceinline__ void tile_epilogue_skip2(const f32x16 (&acc)[XT], Top2 (&st)[XT],
+                                                    int encbase) {
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    const f32x16& a = acc[xt];
+    const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
+                          min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
+                          __builtin_inff());
+    if (__builtin_amdgcn_ballot_w64(m < st[xt].d2) != 0) {
+      float d1 = st[xt].d1, d2 = st[xt].d2;
+      int l1 = -1, l2 = -2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (__builtin_amdgcn_ballot_w64(a[r] < d2) != 0) top2_update(d1, d2, l1, l2, a[r], r);
+      const int o1 = st[xt].i1, o2 = st[xt].i2;
+      st[xt].d1 = d1;
+      st[xt].d2 = d2;
+      st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
+      st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
+    }
+  }
+}
+
 template <int XT>
 __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st)[XT], int encbase) {
 #pragma unroll
@@ -251,7 +279,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st
   }
 }
 
-template <int XT, int NW, bool SKIP>
+template <int XT, int NW, int SKIP>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ cnp, int stages_total, int stages_per_split, int row_tiles,
@@ -305,7 +333,8 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   for (int st = st0; st < st1; ++st) {
     char* sb = smem + ((st - st0) & 1) * kStageBytes;
     compute_tile<XT>(sb, sb + kStageTileBytes, xr, acc, j, h);
-    if constexpr (SKIP) tile_epilogue_skip<XT>(acc, best, (st * 2) * 16);
+    if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, (st * 2) * 16);
+    else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, (st * 2) * 16);
     else tile_epilogue<XT>(acc, best, (st * 2) * 16);
     compute_tile<XT>(sb + kTileK * kRowBytes, sb + kStageTileBytes + kTileK * 4, xr, acc, j, h);
     // every wave is done reading this buffer once it passes the barrier; the stage issued one
@@ -313,7 +342,8 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
-    if constexpr (SKIP) tile_epilogue_skip<XT>(acc, best, (st * 2 + 1) * 16);
+    if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, (st * 2 + 1) * 16);
+    else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, (st * 2 + 1) * 16);
     else tile_epilogue<XT>(acc, best, (st * 2 + 1) * 16);
   }
 
@@ -347,12 +377,14 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
   const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
   const int64_t stages = (k + kStageK - 1) / kStageK;
   const int64_t per = (stages + nsplit - 1) / nsplit;
-  // IC_AMD_VARIANT=0 selects the kernel without the early out (for A/B timing in one build)
-  static const bool no_skip = [] {
+  // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
+  // candidate, 1 = skip tiles no lane can improve, 2 (default) = also skip registers
+  static const int variant = [] {
     const char* v = getenv("IC_AMD_VARIANT");
-    return v && atoi(v) == 0;
+    return v ? atoi(v) : 2;
   }();
-  auto kern = no_skip ? k_top2_partial<kXT, kNW, false> : k_top2_partial<kXT, kNW, true>;
+  auto kern = variant == 0 ? k_top2_partial<kXT, kNW, 0>
+              : variant == 1 ? k_top2_partial<kXT, kNW, 1> : k_top2_partial<kXT, kNW, 2>;
   const int lds = 2 * kStageBytes;
   // per device and cheap, so it is simply repeated on every call
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
