@@ -134,10 +134,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bow")
-    ap.add_argument("--cpu-sample", type=int, default=100_000,
+    ap.add_argument("--cpu-sample", type=int, default=400_000,
                     help="rows of the workload the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (smoke test)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="'gloo' lets several ranks share one GPU to rehearse the multi-rank code "
+                         "path on a one-GPU box (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
     import torch
@@ -148,13 +151,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.dist_backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from image_classification_amd import distributed as D
     from image_classification_amd import ops
