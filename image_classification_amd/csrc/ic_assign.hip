@@ -259,7 +259,8 @@ __device__ __forceinline__ void tile_epilogue_skip2(const f32x16 (&acc)[XT], Top
       int l1 = -1, l2 = -2;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (__builtin_amdgcn_ballot_w64(a[r] < d2) != 0) top2_update(d1, d2, l1, l2, a[r], r);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < d2) != 0, 0))
+          top2_update(d1, d2, l1, l2, a[r], r);
       const int o1 = st[xt].i1, o2 = st[xt].i2;
       st[xt].d1 = d1;
       st[xt].d2 = d2;
