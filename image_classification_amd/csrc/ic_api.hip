@@ -139,7 +139,9 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
 
   const int64_t kpad = (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
-  const int nsplit = ic::assign_choose_nsplit(n, k, ctx->num_cus);
+  ic::AssignPlan plan;
+  ic::assign_plan(n, k, ctx->num_cus, &plan);
+  const int nsplit = plan.nsplit;
   const bool pad = d != ic::kD;
   size_t off = 0;
   const size_t o_cn = off;   off += align_up((size_t)kpad * 4);
@@ -177,9 +179,9 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     ctx->ev_used++;
     IC_HIP(hipEventRecord(ev0, s), "hipEventRecord");
   }
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, nsplit, part, s), "distance/top-2 kernel");
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, plan, part, s), "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
-  IC_HIP(ic::launch_rescore(xs, n, cs, part, nsplit, i1, d1, i2, d2, ratio, mask, rec, s),
+  IC_HIP(ic::launch_rescore(xs, n, cs, part, plan, i1, d1, i2, d2, ratio, mask, rec, s),
          "rescore kernel");
   return finish_call(ctx, s);
 }

@@ -49,20 +49,8 @@ constexpr int kRowsPerWg = kXT * kNW * 32;  // 512
 
 int assign_rows_per_wg() { return kRowsPerWg; }
 
-int assign_choose_nsplit(int64_t n, int64_t k, int num_cus) {
-  // IC_AMD_NSPLIT forces a split (tuning aid); it is clamped to the number of stages
-  static const int forced = [] {
-    const char* v = getenv("IC_AMD_NSPLIT");
-    return v ? atoi(v) : 0;
-  }();
-  if (forced > 0) {
-    const int64_t stages_f = (k + kStageK - 1) / kStageK;
-    const int64_t ns_f = forced < stages_f ? forced : stages_f;
-    const int64_t per_f = (stages_f + ns_f - 1) / ns_f;
-    return (int)((stages_f + per_f - 1) / per_f);
-  }
-  const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
-  const int64_t stages = (k + kStageK - 1) / kStageK;
+// K-split that finishes `row_tiles` row tiles soonest on `num_cus` workgroup slots.
+static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
   const double overhead = 2.0;  // x-tile load + pipeline fill, in units of one stage of work
   int best = 1;
   double best_cost = 1e300;
@@ -79,6 +67,33 @@ int assign_choose_nsplit(int64_t n, int64_t k, int num_cus) {
     }
   }
   return best;
+}
+
+// One workgroup occupies a CU.  Row tiles that fill whole rounds of the machine are searched over
+// the entire codebook by one workgroup each (the longer a lane's scan, the rarer a tile improves
+// its top-2, so ranking gets cheaper, and X is read once); only the row tiles of the last, partly
+// filled round are split along K so that their pieces spread over all CUs.
+void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
+  const int64_t stages = (k + kStageK - 1) / kStageK;
+  p->row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
+  // IC_AMD_NSPLIT forces one split for every row tile (tuning aid)
+  static const int forced = [] {
+    const char* v = getenv("IC_AMD_NSPLIT");
+    return v ? atoi(v) : 0;
+  }();
+  int ns;
+  if (forced > 0) {
+    p->full_tiles = 0;
+    ns = forced;
+  } else {
+    p->full_tiles = p->row_tiles / num_cus * num_cus;
+    const int64_t rem = p->row_tiles - p->full_tiles;
+    ns = rem > 0 ? choose_nsplit(rem, stages, num_cus) : 1;
+  }
+  if (ns > stages) ns = (int)stages;
+  if (ns < 1) ns = 1;
+  p->stages_per_split = (int)((stages + ns - 1) / ns);
+  p->nsplit = (int)((stages + p->stages_per_split - 1) / p->stages_per_split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,19 +298,24 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st
 template <int XT, int NW, int SKIP>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
-    const float* __restrict__ cnp, int stages_total, int stages_per_split, int row_tiles,
-    ic_top2_rec* __restrict__ part) {
+    const float* __restrict__ cnp, int stages_total, int stages_per_split, int full_tiles,
+    int split_tiles, ic_top2_rec* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31;  // descriptor (B column / result column) and codeword row (A row)
   const int h = lane >> 5;  // which half of the 128 components this lane multiplies
 
-  const int rt = blockIdx.x % row_tiles;
-  const int sp = blockIdx.x / row_tiles;
-  const int st0 = sp * stages_per_split;
-  int st1 = st0 + stages_per_split;
-  st1 = st1 < stages_total ? st1 : stages_total;
+  // the first full_tiles workgroups scan the whole codebook; the rest are (row tile, K-split) pairs
+  int rt = blockIdx.x, sp = 0, st0 = 0, st1 = stages_total;
+  if ((int)blockIdx.x >= full_tiles) {
+    const int idx = (int)blockIdx.x - full_tiles;
+    rt = full_tiles + idx % split_tiles;
+    sp = idx / split_tiles;
+    st0 = sp * stages_per_split;
+    st1 = st0 + stages_per_split;
+    st1 = st1 < stages_total ? st1 : stages_total;
+  }
 
   issue_stage<NW>(C, K, cnp, st0, smem, wave, lane);
   if (st0 + 1 < st1) issue_stage<NW>(C, K, cnp, st0 + 1, smem + kStageBytes, wave, lane);
@@ -374,10 +394,10 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, int nsplit, ic_top2_rec* part, hipStream_t s) {
-  const int64_t row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
+                               const float* cn_pad, const AssignPlan& plan, ic_top2_rec* part,
+                               hipStream_t s) {
   const int64_t stages = (k + kStageK - 1) / kStageK;
-  const int64_t per = (stages + nsplit - 1) / nsplit;
+  const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
   // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
   // candidate, 1 = skip tiles no lane can improve, 2 (default) = also skip registers
   static const int variant = [] {
@@ -391,10 +411,11 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  const int64_t grid = row_tiles * nsplit;
+  const int64_t grid = plan.full_tiles + split_tiles * plan.nsplit;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kNW * 64), lds, s, x, n, c, (int)k, cn_pad,
-                     (int)stages, (int)per, (int)row_tiles, part);
+                     (int)stages, plan.stages_per_split, (int)plan.full_tiles, (int)split_tiles,
+                     part);
   return hipGetLastError();
 }
 
@@ -429,6 +450,7 @@ __device__ __forceinline__ float sqdiff8(const f32x4& x0, const f32x4& x1, const
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
                                                  const ic_top2_rec* __restrict__ part, int nsplit,
+                                                 int64_t split_row0,
                                                  int32_t* __restrict__ i1o, float* __restrict__ d1o,
                                                  int32_t* __restrict__ i2o, float* __restrict__ d2o,
                                                  float ratio, uint8_t* __restrict__ mask,
@@ -437,7 +459,8 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   const int64_t stride = (int64_t)gridDim.x * 16;
   for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
     ic_top2_rec b = part[row];
-    for (int s = 1; s < nsplit; ++s) {
+    const int ns = row >= split_row0 ? nsplit : 1;   // rows below split_row0 were not split
+    for (int s = 1; s < ns; ++s) {
       const ic_top2_rec o = part[(int64_t)s * N + row];
       top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
     }
@@ -469,13 +492,13 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
-                          int nsplit, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          const AssignPlan& plan, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
                           uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
   int64_t grid = (n + 15) / 16;
   if (grid > 16384) grid = 16384;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, part, nsplit, i1,
-                     d1, i2, d2, ratio, mask, rec);
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, part, plan.nsplit,
+                     plan.full_tiles * (int64_t)kRowsPerWg, i1, d1, i2, d2, ratio, mask, rec);
   return hipGetLastError();
 }
 

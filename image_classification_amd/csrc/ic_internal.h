@@ -18,8 +18,14 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 // ---- ic_assign.hip ---------------------------------------------------------------------------
 // Rows per workgroup of the distance kernel (x-tile rows kept in registers by one workgroup).
 int assign_rows_per_wg();
-// K-split chosen for a problem (>=1); the partial buffer holds nsplit * n records.
-int assign_choose_nsplit(int64_t n, int64_t k, int num_cus);
+// Decomposition of one search: the first full_tiles row tiles are scanned over the whole
+// codebook by one workgroup each, the remaining ones in nsplit K-splits of stages_per_split
+// stages; the partial buffer holds nsplit * n records.
+struct AssignPlan {
+  int64_t row_tiles, full_tiles;
+  int nsplit, stages_per_split;
+};
+void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p);
 
 hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s);
 // cn_pad[j] = |c_j|^2 for j < k (or a copy of c_sqnorm), +inf for k <= j < kpad.
@@ -28,10 +34,11 @@ hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const 
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
 // part [nsplit][n]: per K-split (cn - 2 x.c, index) best and second best.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, int nsplit, ic_top2_rec* part, hipStream_t s);
+                               const float* cn_pad, const AssignPlan& plan, ic_top2_rec* part,
+                               hipStream_t s);
 // merge the K-splits, recompute the two distances exactly as sum (x-c)^2, order, sqrt, ratio.
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
-                          int nsplit, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          const AssignPlan& plan, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
                           uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
 hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t n,
                              const int64_t* shard_base_host, int64_t* i1, float* d1, int64_t* i2,

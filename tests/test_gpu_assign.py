@@ -68,6 +68,14 @@ def test_config1_100k_by_1k():
     assert agree >= 0.9999
 
 
+def test_rows_beyond_whole_machine_rounds_are_k_split():
+    # 256 row tiles of 512 rows fill one round of the machine and are searched unsplit; the 700
+    # rows after them form a partly filled round whose codebook scan is split over the CUs
+    x = sift_like(256 * 512 + 700, seed=13)
+    c = sift_like(700, seed=14)
+    _check_top2(x, c)
+
+
 def test_ties_lowest_index_wins():
     # duplicated codewords and rounded (integer) data: exact ties; scipy/numpy keep the lowest index
     x = sift_like(1500, seed=5, rounded=True)
