@@ -33,9 +33,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTileK = 32;                          // codewords per MFMA tile
 constexpr int kRowBytes = kD * 4 + 16;              // 528: one 16-byte pad chunk per codeword row
 constexpr int kRowChunks = kRowBytes / 16;          // 33
-constexpr int kStageTileBytes = kStageK * kRowBytes;  // 33792 = 33 wave-instructions of 1 KiB
-constexpr int kStageGlds = kStageTileBytes / 1024;  // 33
-constexpr int kStageBytes = kStageTileBytes + kStageK * 4;  // + 64 squared norms
+constexpr int kStageTileBytes = kStageK * kRowBytes;  // 67584 = 66 wave-instructions of 1 KiB
+constexpr int kStageGlds = kStageTileBytes / 1024;  // 33 per 64 codewords
+constexpr int kTilesPerStage = kStageK / kTileK;
+constexpr int kStageBytes = kStageTileBytes + kStageK * 4;  // + the stage's squared norms
 static_assert(kStageTileBytes % 1024 == 0, "a stage must be a whole number of 1 KiB pieces");
 static_assert(kStageBytes % 16 == 0, "stage buffers must stay 16-byte aligned");
 
@@ -106,7 +107,7 @@ __device__ __forceinline__ void glds4(const float* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-// Stage `st` = codewords [64 st, 64 st + 64) -> LDS buffer sb.  The LDS image of a
+// Stage `st` = codewords [kStageK st, kStageK (st + 1)) -> LDS buffer sb.  The LDS image of a
 // global_load_lds is lane-linear (wave base + 16 * lane), so the padded image (528-byte rows) is
 // produced through the SOURCE address: the lane that lands on 16-byte chunk `pos` of the buffer
 // fetches chunk pos % 33 of codeword row pos / 33 (the 33rd chunk of a row is padding and re-reads
@@ -127,7 +128,7 @@ __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
     const int m = wave + NW * i;
     if (m < kStageGlds) {
       const int pos = m * 64 + lane;
-      int r = (pos * 1986) >> 16;  // pos / 33 for pos < 2112
+      int r = (pos * 1986) >> 16;  // pos / 33, exact for pos < 4224
       int c = pos - r * kRowChunks;
       c = c == kRowChunks - 1 ? 0 : c;
       r = r < last ? r : last;
@@ -135,7 +136,10 @@ __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
       glds16(reinterpret_cast<const float*>(base + voff), sb + m * 1024);
     }
   }
-  if (wave == NW - 1) glds4(cnp + (size_t)st * kStageK + lane, sb + kStageTileBytes);
+#pragma unroll
+  for (int part = 0; part < kStageK / 64; ++part)
+    if (wave == NW - 1 - part)
+      glds4(cnp + (size_t)st * kStageK + part * 64 + lane, sb + kStageTileBytes + part * 256);
 }
 
 struct Top2 {
@@ -353,19 +357,27 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   f32x16 acc[XT];
   for (int st = st0; st < st1; ++st) {
     char* sb = smem + ((st - st0) & 1) * kStageBytes;
-    compute_tile<XT>(sb, sb + kStageTileBytes, xr, acc, j, h);
-    if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, (st * 2) * 16);
-    else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, (st * 2) * 16);
-    else tile_epilogue<XT>(acc, best, (st * 2) * 16);
-    compute_tile<XT>(sb + kTileK * kRowBytes, sb + kStageTileBytes + kTileK * 4, xr, acc, j, h);
-    // every wave is done reading this buffer once it passes the barrier; the stage issued one
-    // iteration ago has landed in the other buffer by then
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
-    if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, (st * 2 + 1) * 16);
-    else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, (st * 2 + 1) * 16);
-    else tile_epilogue<XT>(acc, best, (st * 2 + 1) * 16);
+#pragma unroll
+    for (int t = 0; t < kTilesPerStage; ++t) {
+      // tiles that lie wholly past the end of the codebook (padding of the last stage) are skipped
+      const bool live = (st * kTilesPerStage + t) * kTileK < K;
+      if (live)
+        compute_tile<XT>(sb + t * kTileK * kRowBytes, sb + kStageTileBytes + t * kTileK * 4, xr,
+                         acc, j, h);
+      if (t == kTilesPerStage - 1) {
+        // every wave is done reading this buffer once it passes the barrier; the stage issued one
+        // iteration ago has landed in the other buffer by then
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
+      }
+      if (live) {
+        const int encbase = (st * kTilesPerStage + t) * 16;
+        if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, encbase);
+        else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, encbase);
+        else tile_epilogue<XT>(acc, best, encbase);
+      }
+    }
   }
 
   // decode (tile, register) -> codeword index, fold the two lane halves, store

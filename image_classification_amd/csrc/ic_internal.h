@@ -10,7 +10,7 @@
 namespace ic {
 
 constexpr int kD = 128;      // padded descriptor dimension the MFMA kernel contracts over
-constexpr int kStageK = 64;  // codewords staged in LDS per pipeline stage (2 MFMA tiles of 32)
+constexpr int kStageK = 128;  // codewords staged in LDS per pipeline stage (4 MFMA tiles of 32)
 constexpr int kMaxShards = 64;  // shard bases of ic_top2_merge travel as a kernel argument
 
 static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
