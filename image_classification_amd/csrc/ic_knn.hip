@@ -103,6 +103,94 @@ __global__ __launch_bounds__(kPairThreads) void k_pairdist(
   }
 }
 
+// Few search rows (the usual call of the logo pipeline searches ONE histogram in the index): the
+// tiled kernel above would run a handful of workgroups over the whole width.  Here every wave owns
+// two index rows and streams them once, 16 bytes per lane, against up to four search rows at a
+// time; the work is bounded by reading the index from HBM.
+constexpr int kFewMax = 16;      // search rows up to which this kernel is used (4 per pass)
+constexpr int kFewQ = 4;         // search rows per pass
+constexpr int kFewR = 2;         // index rows per wave
+constexpr int kFewFlush = 8;     // f32 partial sums are folded into float64 every 8 blocks
+
+template <int METRIC, bool VEC>
+__global__ __launch_bounds__(256) void k_pairdist_few(
+    const float* __restrict__ x, int m0, int mq, const float* __restrict__ c, int64_t n, int d,
+    double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r0 = wave * kFewR;
+  if (r0 >= n) return;
+  constexpr int W = VEC ? 4 : 1;          // floats per lane per block
+  const int block = 64 * W;
+  double acc[kFewQ][kFewR];
+#pragma unroll
+  for (int q = 0; q < kFewQ; ++q)
+#pragma unroll
+    for (int r = 0; r < kFewR; ++r) acc[q][r] = 0.0;
+  const float* crow[kFewR];
+#pragma unroll
+  for (int r = 0; r < kFewR; ++r) crow[r] = c + (r0 + r < n ? r0 + r : n - 1) * (int64_t)d;
+  const float* xrow[kFewQ];
+#pragma unroll
+  for (int q = 0; q < kFewQ; ++q) xrow[q] = x + (int64_t)(m0 + (q < mq ? q : mq - 1)) * d;
+
+  for (int d0 = 0; d0 < d; d0 += block * kFewFlush) {
+    float part[kFewQ][kFewR];
+#pragma unroll
+    for (int q = 0; q < kFewQ; ++q)
+#pragma unroll
+      for (int r = 0; r < kFewR; ++r) part[q][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < kFewFlush; ++u) {
+      const int dd = d0 + u * block + lane * W;
+      const bool ok = dd < d;               // with VEC, d % 4 == 0: a lane's four floats are all in or out
+      const int di = ok ? dd : 0;
+      float cv[kFewR][W], xv[kFewQ][W];
+#pragma unroll
+      for (int r = 0; r < kFewR; ++r) {
+        if (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(crow[r] + di);
+          cv[r][0] = t.x; cv[r][1 % W] = t.y; cv[r][2 % W] = t.z; cv[r][3 % W] = t.w;
+        } else {
+          cv[r][0] = crow[r][di];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kFewQ; ++q) {
+        if (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(xrow[q] + di);
+          xv[q][0] = t.x; xv[q][1 % W] = t.y; xv[q][2 % W] = t.z; xv[q][3 % W] = t.w;
+        } else {
+          xv[q][0] = xrow[q][di];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kFewQ; ++q)
+#pragma unroll
+        for (int r = 0; r < kFewR; ++r) {
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < W; ++e) t += pair_term<METRIC>(xv[q][e], cv[r][e]);
+          part[q][r] += ok ? t : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kFewQ; ++q)
+#pragma unroll
+      for (int r = 0; r < kFewR; ++r) acc[q][r] += (double)part[q][r];
+  }
+#pragma unroll
+  for (int q = 0; q < kFewQ; ++q)
+#pragma unroll
+    for (int r = 0; r < kFewR; ++r) {
+      double v = acc[q][r];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && q < mq && r0 + r < n)
+        out[(int64_t)(m0 + q) * n + r0 + r] = METRIC == IC_METRIC_EUCLIDEAN ? sqrt(v) : v;
+    }
+}
+
 struct DistIdx {
   double d;
   int32_t i;
@@ -172,8 +260,32 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_rows(
 
 }  // namespace
 
+template <int METRIC>
+static void launch_few(const float* x, int64_t m, const float* c, int64_t n, int d, double* out,
+                       hipStream_t s) {
+  const dim3 grid((unsigned)((n + 4 * kFewR - 1) / (4 * kFewR)));
+  for (int m0 = 0; m0 < (int)m; m0 += kFewQ) {
+    const int mq = (int)m - m0 < kFewQ ? (int)m - m0 : kFewQ;
+    if (d % 4 == 0)
+      hipLaunchKernelGGL((k_pairdist_few<METRIC, true>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
+    else
+      hipLaunchKernelGGL((k_pairdist_few<METRIC, false>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
+  }
+}
+
 hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n, int d, int metric,
                            double* out, hipStream_t s) {
+  if (m <= kFewMax) {
+    switch (metric) {
+      case IC_METRIC_EUCLIDEAN: launch_few<IC_METRIC_EUCLIDEAN>(x, m, c, n, d, out, s); break;
+      case IC_METRIC_SQEUCLIDEAN: launch_few<IC_METRIC_SQEUCLIDEAN>(x, m, c, n, d, out, s); break;
+      case IC_METRIC_L1: launch_few<IC_METRIC_L1>(x, m, c, n, d, out, s); break;
+      case IC_METRIC_INTERSECTION: launch_few<IC_METRIC_INTERSECTION>(x, m, c, n, d, out, s); break;
+      case IC_METRIC_CHISQR: launch_few<IC_METRIC_CHISQR>(x, m, c, n, d, out, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   const dim3 grid((unsigned)((n + kTile - 1) / kTile), (unsigned)((m + kTile - 1) / kTile));
   const dim3 block(kPairThreads);
   switch (metric) {

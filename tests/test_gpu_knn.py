@@ -23,7 +23,9 @@ def _dev(a):
 
 
 @pytest.mark.parametrize("metric", METRICS)
-@pytest.mark.parametrize("m,n,d", [(1, 1, 1), (3, 5, 33), (70, 130, 64), (65, 64, 1000), (128, 257, 129)])
+@pytest.mark.parametrize("m,n,d", [(1, 1, 1), (3, 5, 33), (70, 130, 64), (65, 64, 1000), (128, 257, 129),
+                                   (1, 301, 10000), (5, 300, 1000), (16, 77, 1001), (17, 77, 1001),
+                                   (2, 9, 2052)])
 def test_pairwise_vs_oracle(metric, m, n, d):
     rng = np.random.default_rng(m * 1000 + n + d)
     x, c = _hists(rng, m, d), _hists(rng, n, d)
