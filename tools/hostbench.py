@@ -35,3 +35,23 @@ print("pinned   H2D of %.0f MB: %.1f ms" % (x.nbytes / 1e6, (time.perf_counter()
 t0 = time.perf_counter()
 ok = np.isfinite(x).all()
 print("np.isfinite check: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+
+# per-image calls, as the reference's flow issues them (one image's descriptors at a time)
+from image_classification_amd import KNNScikit  # noqa: E402
+for rows in (1000, 4000):
+    xi = x[:rows]
+    vq(xi, c)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        vq(xi, c)
+    print("vq(%d x %d) per-image call: %.3f ms" % (rows, k, (time.perf_counter() - t0) / 50 * 1e3))
+hist = np.random.default_rng(0).random((2000, k))
+hist /= hist.sum(1, keepdims=True)
+knn = KNNScikit(3, metric="manhattan")
+knn.train(hist, list(range(2000)))
+knn.get_neighbors(hist[:1], 3)
+t0 = time.perf_counter()
+for _ in range(50):
+    knn.get_neighbors(hist[:1], 3)
+print("KNNScikit(manhattan).get_neighbors(1 x %d vs 2000 logos): %.3f ms"
+      % (k, (time.perf_counter() - t0) / 50 * 1e3))
