@@ -11,7 +11,7 @@ rank per GPU) every rank processes its own 1M descriptors -- the path shards by 
 collective -- so scaling is weak and `value` is the sum over ranks.
 
 The other workloads are the remaining BASELINE configs at their per-GPU size (they are parity /
-sizing cases, run by hand for DESIGN.md, not the line the driver records):
+sizing cases run by hand, not the line the driver records):
   knn     config 3: 4k queries vs a 2M-descriptor index split over N ranks, top-2 + ratio test,
           all-gather + merge of the per-rank records
   kmeans  config 4: one Lloyd iteration over 10M/8 rows, K = 65536, all-reduce of sums/counts
