@@ -5,6 +5,7 @@ libic_hip.so (see ops.py).  The host logic (batching, sharding, the Lloyd loop, 
 takes the backend as an argument so that the multi-process tests can drive that logic on CPU-only
 machines with a checker backend of their own; nothing in the package ever substitutes one.
 """
+import numpy as np
 import torch
 
 from . import device as _device
@@ -12,7 +13,6 @@ from . import ops
 
 
 def _as_f32_rows(a):
-    import numpy as np
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
@@ -39,6 +39,9 @@ class HipBackend(object):
     def codebook(self, c):
         return _device.resident(c, self.device)
 
+    def to_host(self, t):
+        return ops.to_host(t)
+
     # -- searches whose rows start in host memory (numpy): streamed upload -----------------------
     def assign_top1_np(self, x_np, cb, want_dist=True):
         x_np = _as_f32_rows(x_np)
@@ -51,6 +54,21 @@ class HipBackend(object):
         if x_np.shape[0] <= ops.HOST_CHUNK_ROWS:
             return self.assign_top2(self.f32(x_np), cb, ratio)
         return ops.assign_from_host(x_np, cb.c, cb.sqnorm, top2=True, ratio=ratio)
+
+    # -- searches whose rows are a list of host arrays (one per image): threaded gather ---------
+    def assign_top1_parts(self, parts, cb, want_dist=True):
+        total = sum(p.shape[0] for p in parts)
+        if total <= ops.HOST_CHUNK_ROWS // 4:
+            x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
+            return self.assign_top1(self.f32(x_np), cb, want_dist)
+        return ops.assign_from_host_parts(parts, cb.c, cb.sqnorm, top2=False, want_dist=want_dist)
+
+    def assign_top2_parts(self, parts, cb, ratio=0.8):
+        total = sum(p.shape[0] for p in parts)
+        if total <= ops.HOST_CHUNK_ROWS // 4:
+            x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
+            return self.assign_top2(self.f32(x_np), cb, ratio)
+        return ops.assign_from_host_parts(parts, cb.c, cb.sqnorm, top2=True, ratio=ratio)
 
     # -- operators -----------------------------------------------------------------------------
     def assign_top1(self, x, cb, want_dist=True):

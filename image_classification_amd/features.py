@@ -141,13 +141,13 @@ class BagOfWords(object):
             if idesc.descriptors is not None:
                 n = idesc.descriptors.shape[0]
                 if n:
-                    parts.append(np.asarray(idesc.descriptors, dtype=np.float32))
+                    parts.append(np.asarray(idesc.descriptors))
             rows.append(rows[-1] + n)
         offsets = np.asarray(rows, dtype=np.int64)
         if not parts:
             return b.i32(np.empty(0, dtype=np.int32)), offsets
-        allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
-        codes, _ = b.assign_top1_np(allx, b.codebook(self.vocab), want_dist=False)
+        # no host-side concatenation: the per-image arrays are gathered into the upload buffer
+        codes, _ = b.assign_top1_parts(parts, b.codebook(self.vocab), want_dist=False)
         return codes, offsets
 
     def _quantize(self, image_descs):
@@ -155,7 +155,7 @@ class BagOfWords(object):
         if type(self)._build_histogram is BagOfWords._build_histogram:
             b = self._b()
             hists = b.hist(codes, b.i64(offsets), len(self.vocab), self.norm, self.power)
-            return image_descs, hists.cpu().numpy()
+            return image_descs, b.to_host(hists)
         # a subclass builds its own histogram from per-image code lists (SpatialBagOfWords does,
         # model/features.py:1298-1308): hand it what the reference hands it
         host = codes.cpu().numpy()

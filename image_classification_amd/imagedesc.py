@@ -24,11 +24,26 @@ class ImageDesc(object):
             self.desc_cols = 0
         assert self.key_size == self.desc_rows, \
             "Number of keywpoint and descriptors is different"
-        pts = []
-        for k in self.cv_keypoints:
-            pt = k.pt if hasattr(k, "pt") else k
-            pts.append([pt[0], pt[1]])
-        self.keypoints = np.array(pts, dtype=np.float64).reshape(len(pts), 2) if pts else np.array([])
+        self._keypoints = None
+
+    @property
+    def keypoints(self):
+        """[n, 2] float64 array of (x, y); built on first use (quantisation never needs it, and
+        converting a million keypoint objects costs more than searching their descriptors)."""
+        if self._keypoints is None:
+            if self.key_size == 0:
+                self._keypoints = np.array([])
+            elif hasattr(self.cv_keypoints[0], "pt"):
+                self._keypoints = np.array([k.pt for k in self.cv_keypoints],
+                                           dtype=np.float64).reshape(self.key_size, -1)[:, :2]
+            else:   # plain (x, y) pairs or an [n, 2] array: one conversion, no Python loop
+                self._keypoints = np.array(self.cv_keypoints, dtype=np.float64).reshape(
+                    self.key_size, -1)[:, :2]
+        return self._keypoints
+
+    @keypoints.setter
+    def keypoints(self, value):
+        self._keypoints = value
 
     def __eq__(self, other):
         if self.descriptors is None and len(self.cv_keypoints) == 0:

@@ -6,6 +6,7 @@ robust_matching.py, scene_functions.py) are thin layers over these functions.
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -154,6 +155,172 @@ def assign_from_host(x_np, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=Tr
         else:
             assign_top1(xd, c, c_sqnorm, want_dist, out=view)
     return outs
+
+
+_pinned = {}     # (pid, rows, d) -> [pinned tensor, pinned tensor]
+_staging_lock = threading.Lock()   # the staging buffers are shared by all threads of a process
+_gather_pool = None
+GATHER_THREADS = 4
+
+
+def _pinned_pair(rows, d):
+    key = (os.getpid(), rows, d)
+    pair = _pinned.get(key)
+    if pair is None:
+        for k in [k for k in _pinned if k[0] == key[0] and len(k) == 3]:   # one upload size per process
+            del _pinned[k]
+        pair = _pinned[key] = [torch.empty((rows, d), dtype=torch.float32).pin_memory()
+                               for _ in range(2)]
+    return pair
+
+
+def _pool():
+    global _gather_pool
+    if _gather_pool is None or getattr(_gather_pool, "_pid", None) != os.getpid():
+        from concurrent.futures import ThreadPoolExecutor
+        _gather_pool = ThreadPoolExecutor(max_workers=GATHER_THREADS)
+        _gather_pool._pid = os.getpid()
+    return _gather_pool
+
+
+def _copy_rows(dst, src):
+    np.copyto(dst, src, casting="same_kind")
+
+
+def assign_from_host_parts(parts, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=True,
+                           chunk_rows=None):
+    with _staging_lock:
+        return _assign_from_host_parts(parts, c, c_sqnorm, top2, ratio, want_dist, chunk_rows)
+
+
+def _assign_from_host_parts(parts, c, c_sqnorm, top2, ratio, want_dist, chunk_rows):
+    """Search rows held as a LIST of host arrays (one per image, any float dtype, [n_i, d]).
+
+    The reference concatenates such lists on the host before every call; here worker threads
+    gather the pieces straight into one of two page-locked staging buffers (converting to float32
+    on the way), the staging buffer goes to the device on a second stream, and the search of a
+    chunk runs while the next one is being gathered and uploaded.
+    Returns what assign_top1 / assign_top2 return (device tensors covering all rows in order).
+    """
+    chunk_rows = int(chunk_rows or HOST_CHUNK_ROWS)
+    d = c.shape[1]
+    device = c.device
+    n = 0
+    for p in parts:
+        if p.ndim != 2 or p.shape[1] != d:
+            raise ValueError("dimension mismatch: a part has shape %s, codebook %d columns"
+                             % (p.shape, d))
+        n += p.shape[0]
+    if top2:
+        outs = (torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.float32, device=device),
+                torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.float32, device=device),
+                torch.empty(n, dtype=torch.uint8, device=device))
+    else:
+        outs = (torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.float32, device=device) if want_dist else None)
+    if n == 0:
+        return outs
+    # copy jobs (part, lo, hi) grouped into chunks of at most chunk_rows rows
+    chunks, cur_jobs, cur_rows = [], [], 0
+    for p in parts:
+        lo = 0
+        while lo < p.shape[0]:
+            take = min(p.shape[0] - lo, chunk_rows - cur_rows)
+            cur_jobs.append((p, lo, lo + take))
+            cur_rows += take
+            lo += take
+            if cur_rows == chunk_rows:
+                chunks.append((cur_jobs, cur_rows))
+                cur_jobs, cur_rows = [], 0
+    if cur_rows:
+        chunks.append((cur_jobs, cur_rows))
+    stage = _pinned_pair(chunk_rows, d)
+    stage_np = [t.numpy() for t in stage]
+    free = [None, None]            # event after which a staging buffer may be overwritten
+    pool = _pool()
+    cur = torch.cuda.current_stream(device)
+    side = _copy_stream(device)
+    side.wait_stream(cur)
+    row0 = 0
+    for ci, (jobs, rows) in enumerate(chunks):
+        b = ci & 1
+        if free[b] is not None:
+            free[b].synchronize()
+        futures, dst = [], 0
+        for p, lo, hi in jobs:
+            futures.append(pool.submit(_copy_rows, stage_np[b][dst:dst + hi - lo], p[lo:hi]))
+            dst += hi - lo
+        for f in futures:
+            f.result()
+        with torch.cuda.stream(side):
+            xd = torch.empty((rows, d), dtype=torch.float32, device=device)
+            xd.copy_(stage[b][:rows], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        free[b] = ready
+        cur.wait_event(ready)
+        xd.record_stream(cur)
+        view = tuple(o[row0:row0 + rows] if o is not None else None for o in outs)
+        if top2:
+            assign_top2(xd, c, ratio, c_sqnorm, out=view)
+        else:
+            assign_top1(xd, c, c_sqnorm, want_dist, out=view)
+        row0 += rows
+    return outs
+
+
+TO_HOST_CHUNK_BYTES = 16 << 20
+
+
+def to_host(t):
+    """Device tensor -> numpy array.  Large results (histogram blocks of tens of MB) come back
+    through two page-locked staging buffers with the copy into the final array done by worker
+    threads while the next piece is in flight; a plain pageable download runs at a fraction of
+    the link rate."""
+    nbytes = t.numel() * t.element_size()
+    if nbytes < 2 * TO_HOST_CHUNK_BYTES or not t.is_cuda:
+        return t.cpu().numpy()
+    with _staging_lock:
+        return _to_host_staged(t, nbytes)
+
+
+def _to_host_staged(t, nbytes):
+    t = t.contiguous()
+    flat = t.view(-1).view(torch.uint8)
+    out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+    out_bytes = out.reshape(-1).view(np.uint8)
+    key = (os.getpid(), "to_host")
+    stage = _pinned.get(key)
+    if stage is None:
+        stage = _pinned[key] = [torch.empty(TO_HOST_CHUNK_BYTES, dtype=torch.uint8).pin_memory()
+                                for _ in range(2)]
+    stage_np = [s_.numpy() for s_ in stage]
+    pool = _pool()
+    side = _copy_stream(t.device)
+    side.wait_stream(torch.cuda.current_stream(t.device))
+    pending = [None, None]     # (event, lo, hi, future of the previous host copy)
+    copies = []
+    chunks = [(lo, min(nbytes, lo + TO_HOST_CHUNK_BYTES)) for lo in range(0, nbytes, TO_HOST_CHUNK_BYTES)]
+    for ci, (lo, hi) in enumerate(chunks):
+        b = ci & 1
+        if pending[b] is not None:
+            pending[b].result()                      # the host copy out of this buffer is done
+        with torch.cuda.stream(side):
+            stage[b][:hi - lo].copy_(flat[lo:hi], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+
+        def drain(ev=ev, b=b, lo=lo, hi=hi):
+            ev.synchronize()
+            np.copyto(out_bytes[lo:hi], stage_np[b][:hi - lo])
+
+        pending[b] = pool.submit(drain)
+        copies.append(pending[b])
+    for f in copies:
+        f.result()
+    return out
 
 
 def assign_top2_rec(x, c, c_sqnorm=None):

@@ -85,11 +85,10 @@ class RobustMatcher(object):
         rows = [0]
         parts = []
         for n in use:
-            parts.append(np.asarray(image_list[n].descriptors, dtype=np.float32))
+            parts.append(np.asarray(image_list[n].descriptors))
             rows.append(rows[-1] + parts[-1].shape[0])
-        allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
-        i1, _d1, _i2, _d2, mask = b.assign_top2_np(allx, b.codebook(query.descriptors),
-                                                ratio=self.knn_thresh)
+        i1, _d1, _i2, _d2, mask = b.assign_top2_parts(parts, b.codebook(query.descriptors),
+                                                   ratio=self.knn_thresh)
         i1 = i1.cpu().numpy()
         mask = mask.cpu().numpy().astype(bool)
         for slot, n in enumerate(use):
@@ -120,12 +119,11 @@ class RobustMatcher(object):
         rows = [0]
         parts, kps = [], []
         for n in use:
-            parts.append(np.asarray(image_list[n].descriptors, dtype=np.float32))
+            parts.append(np.asarray(image_list[n].descriptors))
             kps.append(np.asarray(image_list[n].keypoints, dtype=np.float64).reshape(-1, 2))
             rows.append(rows[-1] + parts[-1].shape[0])
-        allx = parts[0] if len(parts) == 1 else np.concatenate(parts)
-        i1, _d1, _i2, _d2, mask = b.assign_top2_np(allx, b.codebook(query.descriptors),
-                                                ratio=self.knn_thresh)
+        i1, _d1, _i2, _d2, mask = b.assign_top2_parts(parts, b.codebook(query.descriptors),
+                                                   ratio=self.knn_thresh)
         kp_rows = b.f64(np.ascontiguousarray(np.concatenate(kps)))
         kp_q = b.f64(np.ascontiguousarray(np.asarray(query.keypoints, dtype=np.float64).reshape(-1, 2)))
         out_off, match_q, match_im, pts = b.compact_matches(mask, i1, b.i64(rows), kp_q, kp_rows)

@@ -60,6 +60,12 @@ class CheckerBackend(object):
     def assign_top1_np(self, x_np, cb, want_dist=True):
         return self.assign_top1(self.f32(x_np), cb, want_dist)
 
+    def assign_top1_parts(self, parts, cb, want_dist=True):
+        return self.assign_top1(self.f32(np.concatenate(parts)), cb, want_dist)
+
+    def assign_top2_parts(self, parts, cb, ratio=0.8):
+        return self.assign_top2(self.f32(np.concatenate(parts)), cb, ratio)
+
     def assign_top2_np(self, x_np, cb, ratio=0.8):
         return self.assign_top2(self.f32(x_np), cb, ratio)
 
@@ -135,6 +141,9 @@ class CheckerBackend(object):
         self.calls.append(("knn_rows", tuple(x.shape), tuple(c.shape), metric, k))
         d, i = oracle.kneighbors_metric(c.numpy(), x.numpy(), k, metric)
         return torch.from_numpy(d), torch.from_numpy(i.astype(np.int32))
+
+    def to_host(self, t):
+        return t.numpy()
 
     def u8(self, a):
         return torch.as_tensor(np.asarray(a), dtype=torch.uint8)

@@ -186,6 +186,42 @@ def test_streamed_host_path_equals_device_path():
         vq(bad, c.astype(np.float64))
 
 
+def test_gathered_parts_path_equals_device_path():
+    # a list of per-image arrays (ragged, mixed float dtypes, one empty) is gathered by worker
+    # threads into page-locked staging buffers and uploaded chunk by chunk
+    rng = np.random.default_rng(5)
+    sizes = [int(v) for v in rng.integers(1, 9000, size=40)] + [0, 70000]
+    parts = [sift_like(s, seed=100 + i) if s else np.empty((0, 128), np.float32)
+             for i, s in enumerate(sizes)]
+    parts[3] = parts[3].astype(np.float64)
+    c = sift_like(600, seed=63)
+    cd = _dev(c)
+    cn = ops.row_sqnorm(cd)
+    allx = np.concatenate([p.astype(np.float32) for p in parts])
+    ref = ops.assign_top2(_dev(allx), cd, 0.8, cn)
+    for chunk in (50_000, 131_072):
+        got = ops.assign_from_host_parts(parts, cd, cn, top2=True, ratio=0.8, chunk_rows=chunk)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    idx, dist = ops.assign_from_host_parts(parts, cd, cn, top2=False, want_dist=False)
+    assert dist is None and torch.equal(idx, ref[0])
+    with pytest.raises(ValueError):
+        ops.assign_from_host_parts([np.zeros((3, 64), np.float32)], cd, cn)
+
+
+def test_staged_download_equals_plain_download():
+    # results of tens of MB come back through page-locked staging buffers
+    t = torch.arange(0, 9_000_000, dtype=torch.float64, device="cuda").reshape(3, -1) * 0.5
+    got = ops.to_host(t)
+    assert got.dtype == np.float64 and got.shape == (3, 3_000_000)
+    assert np.array_equal(got, t.cpu().numpy())
+    odd = torch.arange(0, 40_000_003, dtype=torch.uint8, device="cuda")   # not a whole number of chunks
+    assert np.array_equal(ops.to_host(odd), odd.cpu().numpy())
+    small = torch.arange(10, dtype=torch.int32, device="cuda")
+    assert np.array_equal(ops.to_host(small), np.arange(10, dtype=np.int32))
+
+
 def test_errors_are_loud():
     x = _dev(np.zeros((4, 128)))
     with pytest.raises(ValueError):

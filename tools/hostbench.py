@@ -55,3 +55,41 @@ for _ in range(50):
     knn.get_neighbors(hist[:1], 3)
 print("KNNScikit(manhattan).get_neighbors(1 x %d vs 2000 logos): %.3f ms"
       % (k, (time.perf_counter() - t0) / 50 * 1e3))
+
+# BagOfWords.extract over 1000 images x 1000 descriptors held as separate numpy arrays
+from image_classification_amd import BagOfWords  # noqa: E402
+
+
+class _Pre(object):
+    def __init__(self, per_image):
+        self.per_image = per_image
+
+    def extract(self, image_list):
+        return [(self.per_image[i][0], self.per_image[i][1]) for i in image_list]
+
+
+n_img = n // 1000
+kps = [(0.0, 0.0)] * 1000
+per_image = [(kps, x[i * 1000:(i + 1) * 1000].copy()) for i in range(n_img)]
+bow = BagOfWords(_Pre(per_image), vocab=c)
+bow.extract(list(range(4)))
+for rep in range(3):
+    t0 = time.perf_counter()
+    descs, hists = bow.extract(list(range(n_img)))
+    dt = time.perf_counter() - t0
+    print("BagOfWords.extract(%d images x 1000 descriptors, %d words): %.1f ms -> %.3g assignments/s"
+          % (n_img, k, dt * 1e3, n_img * 1000 / dt), flush=True)
+t0 = time.perf_counter()
+image_descs = bow._feature_extract(list(range(n_img)))
+t1 = time.perf_counter()
+codes, offsets = bow._assign_all(image_descs)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+hd = bow._b().hist(codes, bow._b().i64(offsets), len(bow.vocab), "l1", 0.5)
+torch.cuda.synchronize()
+t3 = time.perf_counter()
+hh = hd.cpu().numpy()
+t4 = time.perf_counter()
+print("  ImageDesc objects %.1f ms | gather + upload + search %.1f ms | histogram %.1f ms | "
+      "download of %d MB %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3,
+                                      hh.nbytes >> 20, (t4 - t3) * 1e3))
