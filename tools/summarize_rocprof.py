@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     cut = name.find("(")
     return name[:cut] if cut > 0 else name
 
