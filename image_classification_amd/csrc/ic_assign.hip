@@ -19,8 +19,11 @@
 //   * codeword tiles are staged global -> LDS with global_load_lds (16 B per lane), two stage
 //     buffers; rows are padded to 528 bytes (through the SOURCE address: the LDS image of such a
 //     load is lane-linear) so that ds_read_b128 is bank-conflict free with immediate offsets.
-//   * grid = row tiles x K-splits; every workgroup writes one (value, index) x 2 record per row,
-//     k_rescore merges the splits.
+//   * grid = the row tiles that fill whole rounds of the machine, each scanning the entire
+//     codebook, followed by (row tile, K-split) pairs for the last, partly filled round; every
+//     workgroup writes one (value, index) x 2 record per row, k_rescore merges the splits.
+//   * ranking is gated twice (tile minimum, then per register) because on gfx950 the fp32 MFMA
+//     and the vector ALU never co-execute: every ranking instruction costs MFMA time.
 #include <cstdlib>
 
 #include "ic_internal.h"
@@ -38,11 +41,14 @@ constexpr int kStageGlds = kStageTileBytes / 1024;  // 33 per 64 codewords
 constexpr int kTilesPerStage = kStageK / kTileK;
 constexpr int kStageBytes = kStageTileBytes + kStageK * 4;  // + the stage's squared norms
 static_assert(kStageTileBytes % 1024 == 0, "a stage must be a whole number of 1 KiB pieces");
+static_assert(kStageGlds * 64 <= 8448, "issue_stage divides by 33 with a multiply-shift that is "
+                                       "exact only below 8448");
+static_assert(kStageK % 64 == 0, "the stage's norms are fetched 64 at a time");
 static_assert(kStageBytes % 16 == 0, "stage buffers must stay 16-byte aligned");
 
 // Geometry of the shipped instantiation: 8 waves (two per SIMD: LDS-read latency, barriers and the
 // 18 wait states between an MFMA and a vector read of its result are covered by the partner
-// wave), each holding 2 x 32 descriptors; 206 VGPRs, no spills.  Four waves holding 4 x 32
+// wave), each holding 2 x 32 descriptors; 190 VGPRs, no spills.  Four waves holding 4 x 32
 // descriptors each (one wave per SIMD) made hipcc spill 170+ registers and was dropped.
 constexpr int kXT = 2;
 constexpr int kNW = 8;
