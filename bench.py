@@ -16,7 +16,7 @@ sizing cases run by hand, not the line the driver records):
           all-gather + merge of the per-rank records
   kmeans  config 4: one Lloyd iteration over 10M/8 rows, K = 65536, all-reduce of sums/counts
   video   config 5: 2000 frames x 2k descriptors per GPU, K = 10k, power-L2 histograms
-  logo    config 3 in the reference's own direction: the 2M descriptors of 2000 logo images are
+  logo    config 3 in the reference's own direction: the 2M descriptors of 20 000 logo images are
           searched in the 4k-descriptor index of the query (top-2 + ratio test), matches are
           compacted per logo and verified by the batched homography RANSAC
 
@@ -53,10 +53,10 @@ WORKLOADS = {
     "kmeans": dict(rows=1_250_000, k=65_536,
                    name="BASELINE config 4 (per-GPU share): one Lloyd iteration, 1.25M rows x 65536 "
                         "centroids x 128-d, all-reduce of sums/counts"),
-    "logo": dict(rows=2_000_000, k=4000, images=2000,
-                 name="BASELINE config 3 (reference direction): 2000 logo images x 1000 descriptors "
-                      "searched in a 4k-descriptor query index, top-2 + ratio test, per-logo match "
-                      "compaction, homography RANSAC (46 iterations, threshold 3 px)"),
+    "logo": dict(rows=2_000_000, k=4000, images=20_000,
+                 name="BASELINE config 3 (reference direction): 20 000 logo images x 100 descriptors "
+                      "searched in a 4k-descriptor query index, 5 % planted matches, top-2 + ratio "
+                      "test, per-logo match compaction, homography RANSAC (46 iterations, 3 px)"),
     "knn": dict(rows=4000, k=2_000_000,
                 name="BASELINE config 3: 4k query descriptors vs 2M-descriptor index (split over "
                      "ranks), top-2 + ratio test, all-gather + merge"),
@@ -77,8 +77,18 @@ def cpu_baseline(x_sample, codebook, per_image, norm):
     oracle.build_histogram([code[i * per_image:(i + 1) * per_image] for i in range(n_img)],
                            codebook.shape[0], norm)
     dt = time.perf_counter() - t0
+    one_core = None
+    try:   # the same restatement on one BLAS thread, on a tenth of the sample
+        from threadpoolctl import threadpool_limits
+        ns1 = max(per_image, x_sample.shape[0] // 10 // per_image * per_image)
+        with threadpool_limits(limits=1):
+            t1 = time.perf_counter()
+            oracle.vq(x_sample[:ns1], codebook)
+            one_core = ns1 / (time.perf_counter() - t1)
+    except Exception:
+        pass
     return {"value": x_sample.shape[0] / dt, "unit": "assignments/s", "cores": int(cores),
-            "kind": "port",
+            "kind": "port", "one_core_value": one_core,
             "sample": "%d rows of the workload (same codebook; float64 numpy GEMM + argmin + "
                       "np.histogram), %.1f s" % (x_sample.shape[0], dt)}, code
 
@@ -203,9 +213,9 @@ def main():
         kp_q = torch.rand((k_words, 2), dtype=torch.float64, device=dev, generator=g) * 500
         x = sift_like_device(n_rows, DIM, n_modes=4096, seed=6 + 1000 * rank, device=dev)
         kp_rows = torch.rand((n_rows, 2), dtype=torch.float64, device=dev, generator=g) * 500
-        # every second logo really contains the query: 60 of its rows are noisy copies of query
-        # descriptors whose keypoints follow one homography
-        planted = 60
+        # 5 % of all rows are true matches: every second logo really contains the query, 10 of
+        # its 100 rows are noisy copies of query descriptors whose keypoints follow one homography
+        planted = per // 10
         hom = torch.tensor([[1.1, 0.05, 20.0], [-0.04, 0.95, 10.0], [5e-5, 2e-5, 1.0]],
                            dtype=torch.float64, device=dev)
         rows = (torch.arange(0, n_img, 2, device=dev)[:, None] * per
@@ -258,7 +268,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    phases = None
+    if args.workload == "kmeans" and rank == 0:
+        # one more iteration with a device synchronisation between its phases
+        def timed(fn):
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            return r, (time.perf_counter() - t_a) * 1e3
+        cbk = backend.make_codebook(state["c"])
+        (lab, _), t_assign = timed(lambda: backend.assign_top1(x, cbk, want_dist=False))
+        (sums, counts), t_part = timed(lambda: backend.centroid_partials(x, lab, k_words))
+        t_red = 0.0
+        if allreduce is not None and args.dist_backend == "nccl" and world == 1:
+            _, t_red = timed(lambda: allreduce(sums, counts))
+        _, t_fin = timed(lambda: backend.centroid_finalize(sums, counts, state["c"]))
+        phases = {"assign_ms": t_assign, "centroid_sums_ms": t_part, "allreduce_ms": t_red,
+                  "finalize_ms": t_fin}
+
     if rank == 0:
+        props = torch.cuda.get_device_properties(dev)
         value = world * units_per_step * args.steps / dt_max
         avg_kernel_s = kern_ms / max(1, launches) / 1e3
         achieved = flops_per_launch / avg_kernel_s / 1e12
@@ -289,7 +319,11 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": measured_traffic(args.workload),
                          "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "flops_per_launch": flops_per_launch},
+                         "flops_per_launch": flops_per_launch,
+                         "peak_basis": "256 CU x 256 FLOP/clk x 2.4 GHz; this device reports "
+                                       "%d CUs%s" % (props.multi_processor_count,
+                                                     " at %.0f MHz" % (props.clock_rate / 1e3)
+                                                     if hasattr(props, "clock_rate") else "")},
         }
         if world == 1 and args.cpu_sample > 0 and args.workload in ("bow", "video"):
             per_image = n_rows // w["images"]
@@ -298,9 +332,11 @@ def main():
             base, ref_code = cpu_baseline(x[:ns].cpu().numpy(), cb.cpu().numpy(), per_image, w["norm"])
             base["agreement_with_gpu"] = float(np.mean(ref_code == out_a[:ns].cpu().numpy()))
             out["cpu_baseline"] = base
+        if phases is not None:
+            out["config"]["phase_ms"] = phases
         if world == 1 and args.cpu_sample > 0 and args.workload == "logo":
             out["cpu_baseline"] = cpu_baseline_logo(
-                x, kp_rows, q, kp_q, per, max(1, min(n_img, args.cpu_sample // per)), n_iter,
+                x, kp_rows, q, kp_q, per, max(1, min(n_img, args.cpu_sample // per // 2)), n_iter,
                 out_a, out_b)
         print(json.dumps(out), flush=True)
 

@@ -189,3 +189,36 @@ def test_config2_full_size_properties():
     rd, ri = oracle.topk(xs, cb.cpu().numpy(), 2)
     must, bad, agree = oracle.check_indices(idx[:20000].cpu().numpy(), ri, rd, 0)
     assert bad == 0 and agree >= 0.9999
+    # (8) ragged images (sizes ~ Poisson(1000), two empty ones): same codes, other boundaries
+    rng = np.random.default_rng(8)
+    sizes = rng.poisson(1000, size=n_img)
+    sizes[[17, 600]] = 0
+    sizes = (sizes * (n / sizes.sum())).astype(np.int64)
+    sizes[-1] += n - sizes.sum()
+    rag = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    hr = ops.hist(idx, torch.from_numpy(rag).to(dev), k, "l1")
+    code = idx.cpu().numpy()
+    for i in (0, 17, 18, 599, 600, 601, n_img - 1):
+        ref_row = oracle.build_histogram([code[rag[i]:rag[i + 1]]], k, "l1")[0]
+        assert np.array_equal(hr[i].cpu().numpy(), ref_row)
+
+
+def test_lloyd_trajectory_matches_oracle_downscaled():
+    """BASELINE config 4 scaled down (200k rows, 1024 centroids, same generator and init rule):
+    inertia per iteration and final labels against the float64 restatement of kmeans2."""
+    from image_classification_amd import kmeans2
+    n, k, iters = 200_000, 1024, 4
+    x = sift_like(n, n_modes=4096, seed=7)
+    init = x[np.random.default_rng(8).permutation(n)[:k]].copy()
+    cb, labels = kmeans2(x, init, iter=iters, minit="matrix")
+    ref_cb, ref_labels, history = oracle.kmeans2_matrix(x, init, iters)
+    assert (labels == ref_labels).mean() >= 0.9999
+    err = np.linalg.norm(cb - ref_cb, axis=1) / np.maximum(np.linalg.norm(ref_cb, axis=1), 1e-30)
+    assert err.max() <= 1e-4
+    # inertia (sum of squared distances to the nearest centroid) after every iteration
+    x64 = x.astype(np.float64)
+    for it in (1, 2, 3):
+        cb_i, _ = kmeans2(x, init, iter=it, minit="matrix")
+        _, d_dev = oracle.vq(x64, cb_i.astype(np.float64))
+        _, d_ref = oracle.vq(x64, history[it - 1])
+        assert abs((d_dev ** 2).sum() - (d_ref ** 2).sum()) <= 1e-5 * (d_ref ** 2).sum()
