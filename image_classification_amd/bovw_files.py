@@ -69,6 +69,26 @@ def extract_from_xml(path, tags):
     return ret
 
 
+def load_opencv_matrix(path, name):
+    """One `type_id="opencv-matrix"` node of an OpenCV XML storage file as an ndarray
+    [rows, cols, channels] (what `np.asarray(cv.Load(path, name=name))` gives at
+    vision/utils/scene_functions.py:328).  The node holds <rows>, <cols>, <dt> (element type, with
+    an optional leading channel count such as "2f") and whitespace-separated <data>."""
+    root = ElementTree.parse(path).getroot()
+    nodes = root.findall(name)
+    assert len(nodes) == 1, "Expected exactly one <%s> node, found %d" % (name, len(nodes))
+    node = nodes[0]
+    rows = int(node.find("rows").text)
+    cols = int(node.find("cols").text)
+    dt = node.find("dt").text.strip().strip('"')
+    channels = int(dt[:-1]) if len(dt) > 1 else 1
+    kinds = {"u": np.uint8, "c": np.int8, "w": np.uint16, "s": np.int16, "i": np.int32,
+             "f": np.float32, "d": np.float64}
+    assert dt[-1] in kinds, "unknown OpenCV element type %r" % dt
+    data = np.array(node.find("data").text.split(), dtype=np.float64).astype(kinds[dt[-1]])
+    return data.reshape(rows, cols, channels)
+
+
 def binary_to_ndarray(filename, dims, dtype):
     x = np.fromfile(filename, dtype=dtype)
     return x.reshape(dims)

@@ -44,7 +44,17 @@ def as_device_f32(a, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=torch.float32).contiguous()
     a = np.ascontiguousarray(a, dtype=np.float32)
-    return torch.from_numpy(a).to(device)
+    return _from_numpy(a).to(device)
+
+
+def _from_numpy(a):
+    """torch view of a host array that is only read (read-only memory maps included)."""
+    if a.flags.writeable:
+        return torch.from_numpy(a)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(a)
 
 
 def row_sqnorm(x):
@@ -144,7 +154,7 @@ def assign_from_host(x_np, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=Tr
     for lo in range(0, n, chunk_rows):
         hi = min(n, lo + chunk_rows)
         with torch.cuda.stream(side):
-            xd = torch.from_numpy(x_np[lo:hi]).to(device, non_blocking=True)
+            xd = _from_numpy(x_np[lo:hi]).to(device, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(side)
         cur.wait_event(ready)

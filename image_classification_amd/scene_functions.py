@@ -11,7 +11,7 @@ import numpy as np
 from .backend import default_backend
 
 __all__ = ["compute_vocab_features", "compute_spatial_features", "spatial_cell_weights",
-           "spatial_keypoint_cells"]
+           "spatial_keypoint_cells", "compute_spatial_features_from_xml"]
 
 
 def compute_vocab_features(vocab, feat, backend=None):
@@ -86,3 +86,24 @@ def compute_spatial_features(vocab_feat, keypoints, vocab_size, num_levels, im_w
     out = b.spatial_hist(b.i32(vocab_feat.astype(np.int32)), b.i32(cells), b.f64(weights),
                          int(vocab_size))
     return out.cpu().numpy()
+
+
+def compute_spatial_features_from_xml(extract_path, projected_path, vocab_path, num_levels,
+                                      backend=None):
+    """Spatial-pyramid features straight from the XML / .desc outputs of the vision binaries
+    (vision/utils/scene_functions.py:309-336): the vocabulary and the projected descriptors are raw
+    float32 files next to their XML headers, the keypoint grid and the image geometry come from
+    the extraction XML.  The descriptor file is memory-mapped, so it streams to the device without
+    a second host copy."""
+    from . import bovw_files as bf
+    dims = bf.extract_from_xml(vocab_path, ["numCenters", "dimension"])
+    vocab = bf.binary_to_ndarray("%s.desc" % vocab_path, dims, np.float32)
+    dims = bf.extract_from_xml(projected_path, ["nDescriptors", "cols"])
+    proj = np.memmap("%s.desc" % projected_path, dtype=np.float32, mode="r", shape=tuple(dims))
+    keypoints = bf.load_opencv_matrix(extract_path, "keypoints").squeeze()
+    im_height, im_width, num_images = bf.extract_from_xml(
+        extract_path, ["image_height", "image_width", "nImg"])
+    vocab_feat = compute_vocab_features(vocab, proj, backend=backend).reshape(
+        num_images, keypoints.shape[0])
+    return compute_spatial_features(vocab_feat, keypoints, vocab.shape[0], num_levels, im_width,
+                                    im_height, backend=backend)

@@ -5,6 +5,7 @@ import warnings
 import numpy as np
 import pytest
 
+import oracle
 from image_classification_amd import bovw_files
 from image_classification_amd.features import Vocabulary
 from image_classification_amd.synthetic import sift_like
@@ -63,3 +64,34 @@ def test_vocab_kms_file_to_file(backend, tmp_path):
         bovw_files.vocab_kms(None, fin, 601, fout, backend=backend)     # more codes than rows
     with pytest.raises(IOError):
         bovw_files.vocab_kms(None, str(tmp_path / "missing.xml"), 6, fout, backend=backend)
+
+
+def test_spatial_features_from_xml_files(backend, tmp_path):
+    # the three files the scene pipeline leaves behind: extraction header with the keypoint grid,
+    # projected descriptors, vocabulary
+    from image_classification_amd import bovw_files as bf
+    from image_classification_amd.scene_functions import (compute_spatial_features,
+                                                          compute_spatial_features_from_xml,
+                                                          compute_vocab_features)
+    rng = np.random.default_rng(31)
+    width, height, n_img, dim, k = 120, 90, 5, 24, 40
+    cols, rows = np.meshgrid(np.arange(4, width, 15), np.arange(4, height, 15))
+    kps = np.stack([cols.ravel(), rows.ravel()], axis=1).astype(np.float32)      # (col, row)
+    feats = rng.standard_normal((n_img * len(kps), dim)).astype(np.float32)
+    vocab = rng.standard_normal((k, dim)).astype(np.float32)
+    proj = bf.write_descriptor_file(str(tmp_path / "proj.xml"), feats)
+    voc = bf.write_vocab_file(str(tmp_path / "vocab.xml"), vocab)
+    extract = str(tmp_path / "extract.xml")
+    with open(extract, "w") as f:
+        f.write('<?xml version="1.0"?>\n<opencv_storage>\n'
+                '<keypoints type_id="opencv-matrix">\n  <rows>%d</rows>\n  <cols>1</cols>\n'
+                '  <dt>"2f"</dt>\n  <data>\n    %s</data></keypoints>\n'
+                '<image_height>%d</image_height>\n<image_width>%d</image_width>\n'
+                '<nImg>%d</nImg>\n</opencv_storage>\n'
+                % (len(kps), " ".join("%.1f" % v for v in kps.ravel()), height, width, n_img))
+    assert np.array_equal(bf.load_opencv_matrix(extract, "keypoints").squeeze(), kps)
+    got = compute_spatial_features_from_xml(extract, proj, voc, 3, backend=backend)
+    codes = compute_vocab_features(vocab, feats, backend=backend).reshape(n_img, len(kps))
+    ref = oracle.compute_spatial_features(codes, kps, k, 3, width, height)
+    assert got.shape == (n_img, 21 * k) and np.array_equal(got, ref)
+    assert np.array_equal(codes.ravel(), oracle.compute_vocab_features(vocab, feats))
