@@ -4,7 +4,7 @@
 //   k_count_matches / k_scan_counts / k_compact_matches
 //       ratio-test mask -> per-candidate lists of (query row, candidate row) and of matched
 //       keypoint pairs (x_q, y_q, x_im, y_im), in ascending candidate-row order (stable)
-//   k_ransac_score     one wave per (candidate, iteration): homography through the four sampled
+//   k_ransac_score     one lane per (candidate, iteration): homography through the four sampled
 //                      pairs, inliers among the remaining pairs counted
 //   k_ransac_refit     one wave per candidate: first iteration with the most inliers, direct linear
 //                      transform over its inliers, mean reprojection error, acceptance, mask
@@ -19,7 +19,8 @@ namespace ic {
 
 namespace {
 
-constexpr int kItersPerWg = 16;   // iterations per workgroup of k_ransac_score (4 waves x 4)
+constexpr int kItersPerWg = 64;   // iterations (= lanes) per workgroup of k_ransac_score
+constexpr int kLdsPairs = 1024;   // pairs of a candidate kept in LDS while its iterations run
 constexpr double kProjEps = 0.0000000001;  // "epsilon for non zero division", robust_matching.py:279
 
 // ---------------------------------------------------------------------------------------------
@@ -37,32 +38,30 @@ __global__ __launch_bounds__(64) void k_count_matches(const uint8_t* __restrict_
   if (threadIdx.x == 0) counts[c] = cnt;
 }
 
-// out[0] = 0, out[i + 1] = counts[0] + ... + counts[i]: one workgroup, blocks of 256 with a
-// running carry.
+// out[0] = 0, out[i + 1] = counts[0] + ... + counts[i]: one workgroup; every thread sums a
+// contiguous segment, the 256 segment totals are scanned in LDS, then every thread writes the
+// running sums of its segment.
 __global__ __launch_bounds__(256) void k_scan_counts(const int64_t* __restrict__ counts, int64_t n,
                                                      int64_t* __restrict__ out) {
   __shared__ int64_t buf[256];
-  __shared__ int64_t carry;
-  if (threadIdx.x == 0) {
-    carry = 0;
-    out[0] = 0;
-  }
+  const int64_t seg = (n + 255) / 256;
+  const int64_t lo = (int64_t)threadIdx.x * seg;
+  const int64_t hi = lo + seg < n ? lo + seg : n;
+  int64_t total = 0;
+  for (int64_t i = lo; i < hi; ++i) total += counts[i];
+  buf[threadIdx.x] = total;
   __syncthreads();
-  for (int64_t b = 0; b < n; b += 256) {
-    const int64_t i = b + threadIdx.x;
-    int64_t v = i < n ? counts[i] : 0;
-    buf[threadIdx.x] = v;
+  for (int off = 1; off < 256; off <<= 1) {
+    const int64_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      const int64_t t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-      __syncthreads();
-      buf[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < n) out[i + 1] = carry + buf[threadIdx.x];
+    buf[threadIdx.x] += t;
     __syncthreads();
-    if (threadIdx.x == 255) carry += buf[255];
-    __syncthreads();
+  }
+  int64_t run = buf[threadIdx.x] - total;   // exclusive prefix of this segment
+  if (threadIdx.x == 0) out[0] = 0;
+  for (int64_t i = lo; i < hi; ++i) {
+    run += counts[i];
+    out[i + 1] = run;
   }
 }
 
@@ -216,43 +215,53 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ransac_score: n_inl[cand][it] = pairs outside the sample whose reprojection error is < th
+// k_ransac_score: n_inl[cand][it] = pairs outside the sample whose reprojection error is < th.
+// One LANE per iteration: every lane builds the model of its own sample (no redundant work) and
+// walks the candidate's pairs, which all lanes read at the same address (an LDS broadcast).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ransac_score(
+__global__ __launch_bounds__(kItersPerWg) void k_ransac_score(
     const double* __restrict__ pts_all, const int64_t* __restrict__ off, int n_iter,
-    const int32_t* __restrict__ samples, uint64_t seed, double th, int32_t* __restrict__ n_inl) {
+    const int32_t* __restrict__ samples, uint64_t seed, double th, int min_pairs,
+    int32_t* __restrict__ n_inl) {
+  __shared__ double lpts[kLdsPairs * 4];
   const int64_t cand = blockIdx.x;
   const int64_t p0 = off[cand];
   const int n = (int)(off[cand + 1] - p0);
-  const double* pts = pts_all + p0 * 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int it_end = min(n_iter, ((int)blockIdx.y + 1) * kItersPerWg);
-  for (int it = (int)blockIdx.y * kItersPerWg + wave; it < it_end; it += 4) {
-    int cnt = 0;
-    if (n >= 4) {
-      int s[4];
-      sample4(samples, cand, it, n_iter, n, seed, s);
-      double src[8], dst[8], H[9];
-      load_sample(pts, s, src, dst);
-      homography4(src, dst, H);
-      for (int j = lane; j < n; j += 64) {
-        const double* p = pts + (int64_t)j * 4;
-        const double e = reproj_error(H, p[0], p[1], p[2], p[3]);
-        const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
-        cnt += (!in_sample && e < th) ? 1 : 0;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if (lane == 0) n_inl[cand * n_iter + it] = cnt;
+  const int it = (int)blockIdx.y * kItersPerWg + (int)threadIdx.x;
+  // a candidate with fewer pairs than the acceptance rule demands can never be accepted: no
+  // model is scored for it (the refit kernel rejects it on the same test)
+  if (n < min_pairs) {
+    if (it < n_iter) n_inl[cand * n_iter + it] = 0;
+    return;
   }
+  const double* pts = pts_all + p0 * 4;
+  if (n <= kLdsPairs) {
+    for (int e = threadIdx.x; e < n * 4; e += kItersPerWg) lpts[e] = pts[e];
+    pts = lpts;
+  }
+  __syncthreads();
+  if (it >= n_iter) return;
+  int s[4];
+  sample4(samples, cand, it, n_iter, n, seed, s);
+  double src[8], dst[8], H[9];
+  load_sample(pts, s, src, dst);
+  homography4(src, dst, H);
+  int cnt = 0;
+  for (int j = 0; j < n; ++j) {
+    const double* p = pts + (int64_t)j * 4;
+    const double e = reproj_error(H, p[0], p[1], p[2], p[3]);
+    const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
+    cnt += (!in_sample && e < th) ? 1 : 0;
+  }
+  n_inl[cand * n_iter + it] = cnt;
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_ransac_refit
 // ---------------------------------------------------------------------------------------------
 // In-register Cholesky factor of the packed symmetric 9x9 matrix a (row-major lower triangle,
-// a[r*(r+1)/2 + c], c <= r), in place.
+// a[r*(r+1)/2 + c], c <= r), in place; the diagonal slots end up holding the RECIPROCALS of the
+// factor's diagonal, so that the solves below multiply instead of divide.
 __device__ __forceinline__ void cholesky9(double* a) {
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
@@ -260,8 +269,8 @@ __device__ __forceinline__ void cholesky9(double* a) {
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= a[j * (j + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
     d = sqrt(d);
-    a[j * (j + 1) / 2 + j] = d;
     const double inv = 1.0 / d;
+    a[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 9; ++i) {
       double s = a[i * (i + 1) / 2 + j];
@@ -279,14 +288,14 @@ __device__ __forceinline__ void chol_solve9(const double* L, double* v) {
     double s = v[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= L[i * (i + 1) / 2 + k] * v[k];
-    v[i] = s / L[i * (i + 1) / 2 + i];
+    v[i] = s * L[i * (i + 1) / 2 + i];
   }
 #pragma unroll
   for (int i = 8; i >= 0; --i) {
     double s = v[i];
 #pragma unroll
     for (int k = i + 1; k < 9; ++k) s -= L[k * (k + 1) / 2 + i] * v[k];
-    v[i] = s / L[i * (i + 1) / 2 + i];
+    v[i] = s * L[i * (i + 1) / 2 + i];
   }
 }
 
@@ -303,7 +312,8 @@ __global__ __launch_bounds__(64) void k_ransac_refit(
   uint8_t* mask = mask_all + p0;
   const int lane = threadIdx.x;
 
-  bool ok = n >= 4 && n_iter > 0;
+  const int min_pairs = min_inliers > 4 ? min_inliers : 4;
+  bool ok = n >= min_pairs && n_iter > 0;
   // first iteration with the largest count
   int bc = -1, bi = 0x7fffffff;
   for (int it = lane; it < n_iter; it += 64) {
@@ -472,8 +482,8 @@ hipError_t launch_ransac(const double* pts, const int64_t* off, int64_t n_cand, 
                          double* best_err, int32_t* best_it, uint8_t* mask, hipStream_t s) {
   if (n_iter > 0) {
     const dim3 grid((unsigned)n_cand, (unsigned)((n_iter + kItersPerWg - 1) / kItersPerWg));
-    hipLaunchKernelGGL(k_ransac_score, grid, dim3(256), 0, s, pts, off, n_iter, samples, seed, th,
-                       n_inl_ws);
+    hipLaunchKernelGGL(k_ransac_score, grid, dim3(kItersPerWg), 0, s, pts, off, n_iter, samples, seed, th,
+                       min_inliers > 4 ? min_inliers : 4, n_inl_ws);
   }
   hipLaunchKernelGGL(k_ransac_refit, dim3((unsigned)n_cand), dim3(64), 0, s, pts, off, n_iter,
                      samples, seed, th, min_inliers, accept_mean_err, n_inl_ws, H, n_inliers,

@@ -182,7 +182,8 @@ int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
  *   from a counter-based generator seeded with `seed`;
  *   H [n_cand][9] float64 (zeros when rejected), n_inliers [n_cand] int32 (0 when rejected),
  *   best_err [n_cand] float64, best_iter [n_cand] int32 or NULL, inlier_mask [total] uint8.
- * Candidates with fewer than four pairs are rejected. */
+ * Candidates with fewer than max(4, min_inliers) pairs can never be accepted and are rejected
+ * without scoring (best_iter -1, best_err +inf). */
 int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets, int64_t n_cand,
                          int n_iter, const int32_t* samples, uint64_t seed, double th,
                          int min_inliers, int accept_mean_err, double* H, int32_t* n_inliers,

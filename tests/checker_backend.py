@@ -183,7 +183,7 @@ class CheckerBackend(object):
         for c in range(n_cand):
             data = pts.numpy()[off[c]:off[c + 1]]
             n = data.shape[0]
-            if n < 4 or n_iter < 1:
+            if n < max(4, min_inliers) or n_iter < 1:
                 continue
             if samples is not None:
                 parts = []

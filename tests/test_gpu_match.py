@@ -82,8 +82,9 @@ def _run_case(cands, n_iter, th, seed, min_inliers=10, mean_rule=True):
     H, n_inl, err, best_it, mask = (t.cpu().numpy() for t in (H, n_inl, err, best_it, mask))
     for c, data in enumerate(cands):
         got_mask = mask[off[c]:off[c + 1]]
-        if len(data) < 4:
+        if len(data) < max(4, min_inliers):     # can never be accepted: not even scored
             assert n_inl[c] == 0 and not got_mask.any() and best_it[c] == -1
+            assert not H[c].any() and np.isinf(err[c])
             continue
         info = {}
         fit, ref_mask, ref_err = ransac_ref.ransac(
