@@ -39,15 +39,26 @@ def vq(obs, code_book, check_finite=True, backend=None):
     # more than the whole device search, so it is replaced by a check of the result: with a finite
     # code book, a row holds an inf or NaN exactly when its distance is not finite.
     big = obs_a.size > (1 << 22)
-    if check_finite and not (np.isfinite(cb_a).all() and (big or np.isfinite(obs_a).all())):
-        raise ValueError("array must not contain infs or NaNs")
+    b = backend or default_backend()
+    cbk = b.codebook(cb_a)
+    if check_finite:
+        # the code book's verdict is remembered with its device copy (one scan per code book, not
+        # one per call)
+        cb_ok = getattr(cbk, "host_finite", None)
+        if cb_ok is None:
+            cb_ok = bool(np.isfinite(cb_a).all())
+            try:
+                cbk.host_finite = cb_ok
+            except AttributeError:
+                pass
+        if not (cb_ok and (big or np.isfinite(obs_a).all())):
+            raise ValueError("array must not contain infs or NaNs")
     ct = np.result_type(obs_a.dtype, cb_a.dtype)
     if ct.kind != "f":
         ct = np.dtype(np.float64)
     if obs_a.shape[0] == 0:
         return np.empty(0, dtype=np.int32), np.empty(0, dtype=ct)
-    b = backend or default_backend()
-    idx, dist = b.assign_top1_np(obs_a, b.codebook(cb_a), want_dist=True)
+    idx, dist = b.assign_top1_np(obs_a, cbk, want_dist=True)
     dist = dist.cpu().numpy()
     if check_finite and big and not np.isfinite(dist).all():
         raise ValueError("array must not contain infs or NaNs")
