@@ -76,6 +76,21 @@ def quantize_sharded(x_local, offsets_local, codebook, norm="l1", power=0.5, bac
     return codes, hists, gathered
 
 
+def _staged(t, group):
+    """gloo moves device tensors for all_reduce / broadcast only; the gathers go through host
+    copies when several ranks rehearse the multi-GPU path over gloo (RCCL gathers in place)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(flat, t, group):
+    if _staged(t, group):
+        host = torch.empty(flat.shape, dtype=flat.dtype)
+        dist.all_gather_into_tensor(host, t.cpu().contiguous(), group=group)
+        flat.copy_(host)
+    else:
+        dist.all_gather_into_tensor(flat, t.contiguous(), group=group)
+
+
 def gather_rows(t, group=None):
     """All-gather tensors whose first dimension differs per rank; returns the list of them."""
     rank, n = world(group)
@@ -88,9 +103,9 @@ def gather_rows(t, group=None):
     m = max(sizes)
     padded = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     padded[:t.shape[0]] = t
-    out = [torch.empty_like(padded) for _ in range(n)]
-    dist.all_gather(out, padded, group=group)
-    return [o[:s] for o, s in zip(out, sizes)]
+    flat = torch.empty((n * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    _all_gather_into(flat, padded, group)
+    return [flat[r * m:r * m + s] for r, s in enumerate(sizes)]
 
 
 def make_allreduce(group=None):
@@ -137,7 +152,7 @@ def knn2_index_sharded(queries, index_local, index_base, ratio=0.8, backend=None
         return b.top2_merge(rec.unsqueeze(0).contiguous(), [int(index_base)], ratio)
     rows = rec.shape[0]
     flat = torch.empty((n * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)  # rank r -> rows [r*rows, ..)
+    _all_gather_into(flat, rec, group)                # rank r -> rows [r*rows, (r+1)*rows)
     gathered = flat.view(n, rows, rec.shape[1])
     bases = torch.zeros(n, dtype=torch.int64, device=rec.device)
     bases[rank] = int(index_base)
