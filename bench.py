@@ -202,8 +202,10 @@ def main():
         flops_per_launch = 2.0 * n_rows * k_words * DIM
 
         def step():
-            c, labels, _ = D.lloyd(x, state["c"], 1, backend, allreduce=allreduce)
+            c, labels, _ = D.lloyd(x, state["c"], 1, backend, allreduce=allreduce,
+                                   labels0=state.get("labels"))
             state["c"] = c
+            state["labels"] = labels
             return labels, c
     elif args.workload == "logo":
         n_img, per = w["images"], n_rows // w["images"]

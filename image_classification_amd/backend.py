@@ -71,8 +71,8 @@ class HipBackend(object):
         return ops.assign_from_host_parts(parts, cb.c, cb.sqnorm, top2=True, ratio=ratio)
 
     # -- operators -----------------------------------------------------------------------------
-    def assign_top1(self, x, cb, want_dist=True):
-        return ops.assign_top1(x, cb.c, cb.sqnorm, want_dist)
+    def assign_top1(self, x, cb, want_dist=True, hint=None):
+        return ops.assign_top1(x, cb.c, cb.sqnorm, want_dist, hint=hint)
 
     def assign_top2(self, x, cb, ratio=0.8):
         return ops.assign_top2(x, cb.c, ratio, cb.sqnorm)

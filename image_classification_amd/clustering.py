@@ -29,20 +29,23 @@ def kmeans_assign(x, codebook, backend=None, return_dist=False):
     return idx
 
 
-def lloyd(xd, c0, iters, backend, allreduce=None, on_empty=None):
+def lloyd(xd, c0, iters, backend, allreduce=None, on_empty=None, labels0=None):
     """Run `iters` Lloyd iterations on device-resident rows.
 
     xd: float32 device tensor [n, d] (this process's rows); c0: float32 device tensor [k, d].
     allreduce(sums, counts): in-place sum over processes, or None for a single process.
     on_empty(): called once per iteration that left some cluster without members.
+    labels0: labels from an earlier call with these rows (a guess for the first assignment).
     Returns (codebook device tensor, labels int32 device tensor, empties per iteration).
     """
     cb = backend.make_codebook(c0)
     k = c0.shape[0]
-    labels = None
+    labels = labels0
     empties = []
     for _ in range(int(iters)):
-        labels, _dist = backend.assign_top1(xd, cb, want_dist=False)
+        # the labels of the previous iteration are a guess of the new ones: same result, and the
+        # search skips ranking candidates that cannot beat the guessed centroid
+        labels, _dist = backend.assign_top1(xd, cb, want_dist=False, hint=labels)
         sums, counts = backend.centroid_partials(xd, labels, k)
         if allreduce is not None:
             allreduce(sums, counts)

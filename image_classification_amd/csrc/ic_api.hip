@@ -124,7 +124,8 @@ int finish_call(Ctx* c, hipStream_t s) {
 // Shared body of the three search entry points.
 int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                 const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                uint8_t* mask, ic_top2_rec* rec, void* stream, const char* who) {
+                uint8_t* mask, ic_top2_rec* rec, void* stream, const char* who,
+                const int32_t* hint = nullptr) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "%s: invalid handle", who);
   if (n < 0 || k < 1 || k > 0x7fffffffLL) return fail(IC_EINVAL, "%s: need n >= 0 and 1 <= k < 2^31 (n=%lld k=%lld)", who, (long long)n, (long long)k);
@@ -148,6 +149,7 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   const size_t o_part = off; off += align_up((size_t)nsplit * (size_t)n * sizeof(ic_top2_rec));
   const size_t o_xp = off;   if (pad) off += align_up((size_t)n * ic::kD * 4);
   const size_t o_cp = off;   if (pad) off += align_up((size_t)k * ic::kD * 4);
+  const size_t o_thr = off;  if (hint) off += align_up((size_t)n * 4);
   int rc = ensure_ws(ctx, off);
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
@@ -179,7 +181,12 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     ctx->ev_used++;
     IC_HIP(hipEventRecord(ev0, s), "hipEventRecord");
   }
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, plan, part, s), "distance/top-2 kernel");
+  float* thr = nullptr;
+  if (hint) {
+    thr = reinterpret_cast<float*>(ctx->ws + o_thr);
+    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, cn, hint, thr, s), "hint threshold kernel");
+  }
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, plan, thr, part, s), "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   IC_HIP(ic::launch_rescore(xs, n, cs, part, plan, i1, d1, i2, d2, ratio, mask, rec, s),
          "rescore kernel");
@@ -290,6 +297,15 @@ int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int6
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1: idx is NULL");
   return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
                      nullptr, stream, "ic_assign_top1");
+}
+
+int ic_assign_top1_hint(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                        const float* c_sqnorm, const int32_t* hint, int32_t* idx, float* dist,
+                        void* stream) {
+  if (!idx) return fail(IC_EINVAL, "ic_assign_top1_hint: idx is NULL");
+  if (!hint && n > 0) return fail(IC_EINVAL, "ic_assign_top1_hint: hint is NULL");
+  return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
+                     nullptr, stream, "ic_assign_top1_hint", hint);
 }
 
 int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,

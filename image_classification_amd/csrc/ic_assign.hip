@@ -309,7 +309,7 @@ template <int XT, int NW, int SKIP>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ cnp, int stages_total, int stages_per_split, int full_tiles,
-    int split_tiles, ic_top2_rec* __restrict__ part) {
+    int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -351,8 +351,14 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   Top2 best[XT];
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
-    best[xt].d1 = __builtin_inff();
-    best[xt].d2 = __builtin_inff();
+    // with a caller-supplied bound only candidates below it are ranked at all (index -1 = none)
+    float start = __builtin_inff();
+    if (thr) {
+      int64_t r = row0 + xt * 32 + j;
+      start = thr[r < N ? r : N - 1];
+    }
+    best[xt].d1 = start;
+    best[xt].d2 = start;
     best[xt].i1 = -1;
     best[xt].i2 = -1;
   }
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, const AssignPlan& plan, ic_top2_rec* part,
-                               hipStream_t s) {
+                               const float* cn_pad, const AssignPlan& plan, const float* thr,
+                               ic_top2_rec* part, hipStream_t s) {
   const int64_t stages = (k + kStageK - 1) / kStageK;
   const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
   // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
@@ -433,7 +439,7 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kNW * 64), lds, s, x, n, c, (int)k, cn_pad,
                      (int)stages, plan.stages_per_split, (int)plan.full_tiles, (int)split_tiles,
-                     part);
+                     thr, part);
   return hipGetLastError();
 }
 
@@ -517,6 +523,53 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_to
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, part, plan.nsplit,
                      plan.full_tiles * (int64_t)kRowsPerWg, i1, d1, i2, d2, ratio, mask, rec);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Upper bound, per row, on the value |c|^2 - 2 x.c that the distance kernel will compute for the
+// row's nearest codeword, from a guess `hint[row]` of that codeword (k-means: the label of the
+// previous iteration).  thr = v_hint + 3 B with B = 129 * 2^-24 * (|c|^2 + 2 |x| |c|), a bound
+// on the rounding error of either way of accumulating the 129 terms of v; the true nearest
+// codeword has exact v <= exact v_hint, so both it and the hinted codeword rank below thr.
+__global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict__ X, int64_t N,
+                                                        const float* __restrict__ C, int64_t K,
+                                                        const float* __restrict__ cn,
+                                                        const int32_t* __restrict__ hint,
+                                                        float* __restrict__ thr) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
+    const int hraw = hint[row];
+    const bool ok = hraw >= 0 && hraw < K;
+    const int hh = ok ? hraw : 0;
+    const float* xrow = X + row * kD + sub * 8;
+    const float* crow = C + (int64_t)hh * kD + sub * 8;
+    float dot = 0.f, xn = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dot = __builtin_fmaf(xrow[e], crow[e], dot);
+      xn = __builtin_fmaf(xrow[e], xrow[e], xn);
+    }
+    dot = group16_sum(dot);
+    xn = group16_sum(xn);
+    if (sub == 0) {
+      const float c2 = cn[hh];
+      const float v = c2 - 2.f * dot;
+      const float band = 7.689e-6f * (c2 + 2.f * __builtin_sqrtf(xn * c2));
+      thr[row] = ok ? v + 3.f * band + 1e-30f : __builtin_inff();
+    }
+  }
+}
+
+hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
+                                 const float* cn_pad, const int32_t* hint, float* thr,
+                                 hipStream_t s) {
+  int64_t grid = (n + 15) / 16;
+  if (grid > 16384) grid = 16384;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_hint_threshold, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, k, cn_pad,
+                     hint, thr);
   return hipGetLastError();
 }
 

@@ -34,8 +34,12 @@ hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const 
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
 // part [nsplit][n]: per K-split (cn - 2 x.c, index) best and second best.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, const AssignPlan& plan, ic_top2_rec* part,
-                               hipStream_t s);
+                               const float* cn_pad, const AssignPlan& plan, const float* thr,
+                               ic_top2_rec* part, hipStream_t s);
+// thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
+hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
+                                 const float* cn_pad, const int32_t* hint, float* thr,
+                                 hipStream_t s);
 // merge the K-splits, recompute the two distances exactly as sum (x-c)^2, order, sqrt, ratio.
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
                           const AssignPlan& plan, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,

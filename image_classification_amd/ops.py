@@ -78,9 +78,11 @@ def _check_pair(x, c):
         raise ValueError("x and codebook live on different devices")
 
 
-def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None):
+def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None, hint=None):
     """idx[i] = argmin_j |x_i - c_j| (lowest j on ties), dist[i] = that Euclidean distance.
-    `out` = (idx, dist) preallocated contiguous device tensors (views are fine)."""
+    `out` = (idx, dist) preallocated contiguous device tensors (views are fine).
+    `hint` = int32 [n] guess of idx (e.g. the labels of the previous k-means iteration): same
+    result, less ranking work when the guess is good."""
     _check_pair(x, c)
     dev = _dev_index(x)
     n = x.shape[0]
@@ -89,6 +91,14 @@ def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None):
     else:
         idx = torch.empty(n, dtype=torch.int32, device=x.device)
         dist = torch.empty(n, dtype=torch.float32, device=x.device) if want_dist else None
+    if hint is not None:
+        if hint.dtype != torch.int32 or hint.shape[0] != n or hint.device != x.device:
+            raise ValueError("hint must be an int32 device tensor with one entry per row of x")
+        rc = _lib.load().ic_assign_top1_hint(
+            _lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1], _ptr(c_sqnorm),
+            _ptr(hint.contiguous()), _ptr(idx), _ptr(dist), _stream_ptr(dev))
+        _lib.check(rc, "ic_assign_top1_hint")
+        return idx, dist
     rc = _lib.load().ic_assign_top1(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
                                     _ptr(c_sqnorm), _ptr(idx), _ptr(dist), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top1")

@@ -81,6 +81,14 @@ int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, vo
 int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                    const float* c_sqnorm, int32_t* idx, float* dist, void* stream);
 
+/* ic_assign_top1 with a guess of every row's nearest codeword (k-means: the labels of the
+ * previous Lloyd iteration inside kmeans2, vision/facerec/face_indexing.py:158).  The result is
+ * the same as without the guess; a good guess lets the kernel skip ranking candidates that
+ * cannot beat it.  hint [n] int32, values outside [0,k) mean "no guess". */
+int ic_assign_top1_hint(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                        const float* c_sqnorm, const int32_t* hint, int32_t* idx, float* dist,
+                        void* stream);
+
 /* Two nearest index rows per search row, ascending (distance, index), plus the ratio test
  * mask[i] = d1[i] < d2[i] * ratio.  Replaces KNeighborsClassifier.kneighbors(x, 2) at
  * model/classifiers.py:195-197 as used by model/robust_matching.py:80, and the Python ratio

@@ -52,7 +52,7 @@ class CheckerBackend(object):
         self.calls.append(("search", tuple(x.shape), cb.shape))
         return oracle.topk(x.numpy(), cb.c.numpy(), kk)
 
-    def assign_top1(self, x, cb, want_dist=True):
+    def assign_top1(self, x, cb, want_dist=True, hint=None):
         d, i = self._top(x, cb, 1)
         idx = torch.from_numpy(i[:, 0].astype(np.int32))
         return idx, (torch.from_numpy(d[:, 0].astype(np.float32)) if want_dist else None)

@@ -222,6 +222,35 @@ def test_staged_download_equals_plain_download():
     assert np.array_equal(ops.to_host(small), np.arange(10, dtype=np.int32))
 
 
+def test_hinted_search_gives_the_same_answer():
+    # guesses of every quality: exact, stale (previous codebook), random, out of range, worst
+    x = sift_like(200_000, seed=71)
+    c = sift_like(3000, n_modes=1024, seed=72)
+    xd, cd = _dev(x), _dev(c)
+    cn = ops.row_sqnorm(cd)
+    idx, dist = ops.assign_top1(xd, cd, cn)
+    rng = np.random.default_rng(1)
+    stale_cb = _dev(c + rng.normal(0, 8.0, size=c.shape).astype(np.float32))
+    stale, _ = ops.assign_top1(xd, stale_cb)
+    rand = torch.from_numpy(rng.integers(0, 3000, size=len(x)).astype(np.int32)).cuda()
+    bad = torch.full((len(x),), -7, dtype=torch.int32, device="cuda")
+    bad[::2] = 3000
+    far = torch.cdist(xd[:5000], cd).argmax(1).int()
+    for hint in (idx, stale, rand, bad):
+        hi, hd = ops.assign_top1(xd, cd, cn, hint=hint)
+        assert torch.equal(hi, idx) and torch.equal(hd, dist)
+    hi, hd = ops.assign_top1(xd[:5000], cd, cn, hint=far)
+    assert torch.equal(hi, idx[:5000]) and torch.equal(hd, dist[:5000])
+    # ties and exact hits keep the lowest index
+    c2 = np.concatenate([c[:100], c[:100]])
+    i_ref, _ = ops.assign_top1(_dev(c[:100]), _dev(c2))
+    i_hint, d_hint = ops.assign_top1(_dev(c[:100]), _dev(c2),
+                                     hint=(torch.arange(100, device="cuda") + 100).int())
+    assert torch.equal(i_hint, i_ref) and torch.all(d_hint == 0)
+    with pytest.raises(ValueError):
+        ops.assign_top1(xd, cd, cn, hint=idx[:10])
+
+
 def test_errors_are_loud():
     x = _dev(np.zeros((4, 128)))
     with pytest.raises(ValueError):
