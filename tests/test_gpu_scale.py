@@ -1,0 +1,95 @@
+"""Size-independent properties at the full per-GPU sizes of BASELINE configs 3, 4 and 5 (config 2
+is covered in test_gpu_reduce.py).  No CPU oracle can run at these sizes; bounded samples are
+checked against it."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from image_classification_amd import ops
+from image_classification_amd.synthetic import image_offsets, sift_like_device
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_config3_logo_search_both_directions():
+    # 4k query descriptors, 2M database descriptors, 5 % of the database rows are noisy copies
+    nq, ndb = 4000, 2_000_000
+    q = sift_like_device(nq, n_modes=4096, seed=5, device=DEV)
+    db = sift_like_device(ndb, n_modes=4096, seed=6, device=DEV)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    planted = torch.randperm(ndb, device=DEV, generator=g)[:ndb // 20]
+    src = torch.randint(0, nq, (planted.numel(),), device=DEV, generator=g)
+    db[planted] = q[src] + 2.0 * torch.randn((planted.numel(), 128), device=DEV, generator=g)
+    # (i) reference direction: database rows searched in the query index
+    i1, d1, i2, d2, mask = ops.assign_top2(db, q, 0.8)
+    assert torch.equal(i1[planted].long(), src)              # every planted row finds its source
+    assert mask[planted].float().mean() > 0.999               # and passes the ratio test
+    rest = torch.ones(ndb, dtype=torch.bool, device=DEV)
+    rest[planted] = False
+    assert mask[rest].float().mean() < 0.02                   # unrelated rows rarely do
+    assert torch.all(d1 <= d2)
+    # row-sharded (8 blocks of 250k) == unsharded
+    for lo in range(0, ndb, 250_000):
+        part = ops.assign_top2(db[lo:lo + 250_000], q, 0.8)
+        assert torch.equal(part[0], i1[lo:lo + 250_000]) and torch.equal(part[4], mask[lo:lo + 250_000])
+    # (ii) transposed: queries searched in the database, 8 index shards merged
+    full = ops.assign_top2(q, db, 0.8)
+    bounds = list(range(0, ndb + 1, 250_000))
+    recs = torch.stack([ops.assign_top2_rec(q, db[lo:hi]) for lo, hi in zip(bounds[:-1], bounds[1:])])
+    merged = ops.top2_merge(recs.contiguous(), bounds[:-1], 0.8)
+    same = (merged[0] == full[0].long()) & (merged[2] == full[2].long())
+    assert same.float().mean() > 0.999
+    assert torch.equal(merged[1][same], full[1][same])
+    # bounded sample against the float64 oracle (queries vs the first 200k database rows)
+    rd, ri = oracle.topk(q[:500].cpu().numpy(), db[:200_000].cpu().numpy(), 3)
+    got = ops.assign_top2(q[:500], db[:200_000], 0.8)
+    for col, rank in ((0, 0), (2, 1)):
+        must, bad, agree = oracle.check_indices(got[col].cpu().numpy(), ri, rd, rank)
+        assert bad == 0 and agree > 0.995
+
+
+def test_config4_one_lloyd_iteration_share():
+    # one GPU's share of 10M x 65536: 1.25M rows
+    n, k = 1_250_000, 65_536
+    x = sift_like_device(n, n_modes=4096, seed=7, device=DEV)
+    c = x[torch.randperm(n, device=DEV)[:k]].clone()
+    idx, dist = ops.assign_top1(x, c)
+    sums, counts = ops.centroid_partials(x, idx, k)
+    assert int(counts.sum()) == n and torch.equal(counts, torch.bincount(idx.long(), minlength=k))
+    assert torch.allclose(sums.sum(0), x.double().sum(0), rtol=1e-11)
+    new_c, has = ops.centroid_finalize(sums, counts, c)
+    assert torch.equal(has.bool(), counts > 0)
+    # Lloyd's guarantee: assigning to the new centroids does not raise the inertia
+    idx2, dist2 = ops.assign_top1(x, new_c, hint=idx)
+    idx2_plain, dist2_plain = ops.assign_top1(x, new_c)
+    assert torch.equal(idx2, idx2_plain) and torch.equal(dist2, dist2_plain)
+    assert float((dist2.double() ** 2).sum()) <= float((dist.double() ** 2).sum()) * (1 + 1e-9)
+    # every initial centroid is a data row: that row is at distance 0 from its own centroid
+    # sample against the oracle
+    xs = x[:3000].cpu().numpy()
+    rd, ri = oracle.topk(xs, c.cpu().numpy(), 2)
+    must, bad, agree = oracle.check_indices(idx[:3000].cpu().numpy(), ri, rd, 0)
+    assert bad == 0 and agree >= 0.999
+
+
+def test_config5_video_batch_share():
+    # 2000 frames x 2000 descriptors, 10k words, signed-square-root + L2 histograms
+    n_img, per, k = 2000, 2000, 10_000
+    x = sift_like_device(n_img * per, n_modes=2048, seed=9, device=DEV)
+    cb = sift_like_device(k, n_modes=2048, seed=4, device=DEV)
+    offsets = torch.from_numpy(image_offsets(n_img, per)).to(DEV)
+    idx, _ = ops.assign_top1(x, cb, want_dist=False)
+    h = ops.hist(idx, offsets, k, "power_l2", 0.5)
+    assert torch.allclose((h * h).sum(1), torch.ones(n_img, dtype=torch.float64, device=DEV), rtol=1e-12)
+    raw = ops.hist(idx, offsets, k, "none")
+    assert int(raw.sum()) == n_img * per
+    ref = oracle.build_histogram([idx[i * per:(i + 1) * per].cpu().numpy() for i in (0, 999, 1999)],
+                                 k, "power_l2", 0.5)
+    assert oracle.check_close(h[[0, 999, 1999]].cpu().numpy(), ref, rel=1e-12, abs_floor=1e-300) <= 1e-12
+    l1 = ops.hist(idx, offsets, k, "l1")
+    assert np.array_equal(l1[[0, 999, 1999]].cpu().numpy(),
+                          oracle.build_histogram([idx[i * per:(i + 1) * per].cpu().numpy()
+                                                  for i in (0, 999, 1999)], k, "l1"))
