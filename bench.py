@@ -336,6 +336,14 @@ def main():
             out["cpu_baseline"] = base
         if phases is not None:
             out["config"]["phase_ms"] = phases
+        if args.workload in ("bow", "video") and args.cpu_sample > 0:
+            # every row of the workload against the direct float32 search on the device (no norm
+            # expansion; outside the timed region)
+            e1, ed1, _e2, ed2, _m = ops.assign_top2_exact(x, cb)
+            gap = (ed2 - ed1) > 1e-5 * ed1
+            out["parity"] = {"checked_rows": int(n_rows), "checker": "direct float32 search on the device",
+                             "agreement": float((out_a == e1).float().mean()),
+                             "mismatches_where_gap_exceeds_1e-5": int(((out_a != e1) & gap).sum())}
         if world == 1 and args.cpu_sample > 0 and args.workload == "logo":
             out["cpu_baseline"] = cpu_baseline_logo(
                 x, kp_rows, q, kp_q, per, max(1, min(n_img, args.cpu_sample // per // 2)), n_iter,

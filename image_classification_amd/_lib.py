@@ -41,6 +41,7 @@ _SIGNATURES = {
     "ic_assign_top1": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
     "ic_assign_top1_hint": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _p],
     "ic_assign_top2": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _c_f, _p, _p],
+    "ic_assign_top2_exact": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _c_f, _p, _p],
     "ic_assign_top2_rec": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p],
     "ic_top2_merge": [_p, _p, _c_int, _c_i64, ctypes.POINTER(_c_i64), _p, _p, _p, _p, _c_f, _p, _p],
     "ic_hist": [_p, _p, _p, _c_i64, _c_i64, _c_int, _c_d, _p, _p],

@@ -316,6 +316,39 @@ int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int6
                      "ic_assign_top2");
 }
 
+int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                         int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                         uint8_t* mask, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_assign_top2_exact: invalid handle");
+  if (n < 0 || k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kD)
+    return fail(IC_EINVAL, "ic_assign_top2_exact: bad shape n=%lld k=%lld d=%d", (long long)n,
+                (long long)k, d);
+  if (n == 0) return IC_OK;
+  if (!x || !c || !i1) return fail(IC_EINVAL, "ic_assign_top2_exact: NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  const float* xs = x;
+  const float* cs = c;
+  if (d != ic::kD) {
+    const size_t o_cp = align_up((size_t)n * ic::kD * 4);
+    int rc = ensure_ws(ctx, o_cp + align_up((size_t)k * ic::kD * 4));
+    if (rc) return rc;
+    rc = order_after_previous(ctx, s);
+    if (rc) return rc;
+    float* xp = reinterpret_cast<float*>(ctx->ws);
+    float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
+    IC_HIP(ic::launch_pad_rows(x, n, d, xp, s), "pad descriptors");
+    IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
+    xs = xp;
+    cs = cp;
+  }
+  IC_HIP(ic::launch_exact_top2(xs, n, cs, k, i1, d1, i2, d2, ratio, mask, s), "direct search kernel");
+  return d != ic::kD ? finish_call(ctx, s) : IC_OK;
+}
+
 int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                        const float* c_sqnorm, ic_top2_rec* rec, void* stream) {
   if (!rec) return fail(IC_EINVAL, "ic_assign_top2_rec: rec is NULL");

@@ -153,6 +153,15 @@ struct Top2 {
   int i1, i2;
 };
 
+struct FinalOutExact {   // outputs of k_exact_top2 (any pointer may be null)
+  int32_t* i1;
+  float* d1;
+  int32_t* i2;
+  float* d2;
+  float ratio;
+  uint8_t* mask;
+};
+
 // Strict '<' and ascending visiting order keep the lowest index on ties, as scipy's _vq.vq scan
 // and numpy's argmin do.
 __device__ __forceinline__ void top2_update(float& d1r, float& d2r, int& i1r, int& i2r, float v,
@@ -570,6 +579,102 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_hint_threshold, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, k, cn_pad,
                      hint, thr);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct search: sum (x - c)^2 in float32 for every (row, codeword) pair, no norm expansion and
+// therefore no cancellation.  Ten times the work of the matrix-core kernel on the vector ALU; it
+// exists as the on-device checker for sizes no CPU oracle can handle and for callers that want
+// distances free of the expansion's rounding.  16 rows per workgroup live in LDS (every lane
+// reads the same row element: a broadcast), every thread walks codewords t, t+256, ... keeping a
+// top-2 per row, and the 256 partial top-2s are folded by (distance, index).
+constexpr int kExactRows = 16;
+
+__global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X, int64_t N,
+                                                    const float* __restrict__ C, int K,
+                                                    FinalOutExact fin) {
+  __shared__ __attribute__((aligned(16))) float xs[kExactRows][kD];
+  __shared__ float rd1[4][kExactRows], rd2[4][kExactRows];
+  __shared__ int ri1[4][kExactRows], ri2[4][kExactRows];
+  const int64_t r0 = (int64_t)blockIdx.x * kExactRows;
+  for (int e = threadIdx.x; e < kExactRows * kD; e += 256) {
+    const int64_t r = r0 + e / kD;
+    xs[e / kD][e % kD] = X[(r < N ? r : N - 1) * kD + e % kD];
+  }
+  __syncthreads();
+  float d1[kExactRows], d2[kExactRows];
+  int i1[kExactRows], i2[kExactRows];
+#pragma unroll
+  for (int r = 0; r < kExactRows; ++r) {
+    d1[r] = d2[r] = __builtin_inff();
+    i1[r] = i2[r] = -1;
+  }
+  for (int j = threadIdx.x; j < K; j += 256) {
+    const float* crow = C + (int64_t)j * kD;
+    float acc[kExactRows];
+#pragma unroll
+    for (int r = 0; r < kExactRows; ++r) acc[r] = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < kD; ch += 32) {
+      f32x4 cv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + ch + q * 4);
+#pragma unroll
+      for (int r = 0; r < kExactRows; ++r) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[r][ch + q * 4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = xv[e] - cv[q][e];
+            acc[r] = __builtin_fmaf(t, t, acc[r]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kExactRows; ++r) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < kExactRows; ++r) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float od1 = __shfl_xor(d1[r], off), od2 = __shfl_xor(d2[r], off);
+      const int oi1 = __shfl_xor(i1[r], off), oi2 = __shfl_xor(i2[r], off);
+      top2_merge_pairs(d1[r], i1[r], d2[r], i2[r], od1, oi1, od2, oi2);
+    }
+    if (lane == 0) {
+      rd1[wave][r] = d1[r]; ri1[wave][r] = i1[r];
+      rd2[wave][r] = d2[r]; ri2[wave][r] = i2[r];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kExactRows) {
+    const int r = threadIdx.x;
+    float a1 = rd1[0][r], a2 = rd2[0][r];
+    int j1 = ri1[0][r], j2 = ri2[0][r];
+    for (int w = 1; w < 4; ++w) top2_merge_pairs(a1, j1, a2, j2, rd1[w][r], ri1[w][r], rd2[w][r], ri2[w][r]);
+    const int64_t row = r0 + r;
+    if (row < N) {
+      const float e1 = __builtin_sqrtf(a1), e2 = __builtin_sqrtf(a2);
+      if (fin.i1) fin.i1[row] = j1;
+      if (fin.d1) fin.d1[row] = e1;
+      if (fin.i2) fin.i2[row] = j2;
+      if (fin.d2) fin.d2[row] = e2;
+      if (fin.mask) fin.mask[row] = (e1 < e2 * fin.ratio) ? 1 : 0;
+    }
+  }
+}
+
+hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t k, int32_t* i1,
+                             float* d1, int32_t* i2, float* d2, float ratio, uint8_t* mask,
+                             hipStream_t s) {
+  const int64_t grid = (n + kExactRows - 1) / kExactRows;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_exact_top2, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, (int)k,
+                     FinalOutExact{i1, d1, i2, d2, ratio, mask});
   return hipGetLastError();
 }
 

@@ -48,6 +48,11 @@ hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t 
                              const int64_t* shard_base_host, int64_t* i1, float* d1, int64_t* i2,
                              float* d2, float ratio, uint8_t* mask, hipStream_t s);
 
+// direct float32 search (sum (x-c)^2 per pair, no expansion): the on-device checker
+hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t k, int32_t* i1,
+                             float* d1, int32_t* i2, float* d2, float ratio, uint8_t* mask,
+                             hipStream_t s);
+
 // ---- ic_reduce.hip ---------------------------------------------------------------------------
 // cell_w (nullable): per-cell weights, bin b belongs to cell b / cell_k (raw counts only).
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,

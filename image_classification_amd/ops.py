@@ -126,6 +126,23 @@ def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True, out=None):
     return i1, d1, i2, d2, mask
 
 
+def assign_top2_exact(x, c, ratio=0.8):
+    """assign_top2 by direct float32 differences (no norm expansion): the slow on-device checker."""
+    _check_pair(x, c)
+    dev = _dev_index(x)
+    n = x.shape[0]
+    i1 = torch.empty(n, dtype=torch.int32, device=x.device)
+    i2 = torch.empty(n, dtype=torch.int32, device=x.device)
+    d1 = torch.empty(n, dtype=torch.float32, device=x.device)
+    d2 = torch.empty(n, dtype=torch.float32, device=x.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+    rc = _lib.load().ic_assign_top2_exact(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0],
+                                          x.shape[1], _ptr(i1), _ptr(d1), _ptr(i2), _ptr(d2),
+                                          float(ratio), _ptr(mask), _stream_ptr(dev))
+    _lib.check(rc, "ic_assign_top2_exact")
+    return i1, d1, i2, d2, mask
+
+
 _copy_streams = {}
 HOST_CHUNK_ROWS = 1 << 17   # rows per upload chunk of the streamed host path (64 MiB of float32)
 

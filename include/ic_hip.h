@@ -98,6 +98,14 @@ int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int6
                    const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2,
                    float ratio, uint8_t* mask, void* stream);
 
+/* Same contract as ic_assign_top2, computed by direct differences sum (x-c)^2 in float32 on the
+ * vector ALU (what scipy's _vq.vq does for small inputs, model/features.py:1166) instead of the
+ * norm expansion on the matrix cores: about ten times slower, free of the expansion's rounding.
+ * It is the on-device checker of the fast path at sizes no CPU oracle can handle. */
+int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                         int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                         uint8_t* mask, void* stream);
+
 /* Same search, but the result is written as one ic_top2_rec per row (indices local to this
  * index shard) for a later ic_top2_merge.  No counterpart in the reference: it exists because
  * the index side of model/robust_matching.py:73-80 is sharded over GPUs. */

@@ -251,6 +251,45 @@ def test_hinted_search_gives_the_same_answer():
         ops.assign_top1(xd, cd, cn, hint=idx[:10])
 
 
+@pytest.mark.parametrize("n,k,d", [(1000, 300, 128), (37, 5, 64), (513, 1, 128), (2000, 700, 33)])
+def test_direct_search_vs_oracle(n, k, d):
+    # the slow kernel without the norm expansion: the strict rule holds even for near ties
+    rng = np.random.default_rng(n + k)
+    x = (rng.standard_normal((n, d)) * 40).astype(np.float32)
+    c = (rng.standard_normal((k, d)) * 40).astype(np.float32)
+    if k > 4:
+        c[k - 1] = c[0]
+        x[:3] = c[:3]
+    i1, d1, i2, d2, mask = (t.cpu().numpy() for t in ops.assign_top2_exact(_dev(x), _dev(c), 0.8))
+    rd, ri = oracle.topk(x, c, min(3, k))
+    if k == 1:
+        assert (i1 == 0).all() and (i2 == -1).all() and np.isinf(d2).all()
+        assert oracle.check_close(d1, rd[:, 0], abs_floor=1e-4) <= DIST_REL
+        return
+    must, bad, agree = oracle.check_indices(i1, ri, rd, 0)
+    assert bad == 0 and agree > 0.999
+    assert oracle.check_close(d1[i1 == ri[:, 0]], rd[i1 == ri[:, 0], 0], abs_floor=1e-4) <= DIST_REL
+    if k >= 3:
+        must, bad, agree = oracle.check_indices(i2, ri, rd, 1)
+        assert bad == 0
+
+
+def test_one_dimensional_near_ties_direct_search_is_strict():
+    # rows far closer to their neighbours than float32 resolves from the norms: the matrix-core
+    # path may pick a neighbour inside that resolution, the direct search may not
+    rng = np.random.default_rng(38)
+    x = (rng.standard_normal((2059, 1)) * 300).astype(np.float32)
+    c = (rng.standard_normal((430, 1)) * 300).astype(np.float32)
+    rd, ri = oracle.topk(x, c, 3)
+    e = [t.cpu().numpy() for t in ops.assign_top2_exact(_dev(x), _dev(c), 0.8)]
+    for col, rank in ((0, 0), (2, 1)):
+        must, bad, _ = oracle.check_indices(e[col], ri, rd, rank)
+        assert bad == 0
+    f = [t.cpu().numpy() for t in ops.assign_top2(_dev(x), _dev(c), 0.8)]
+    assert oracle.mismatches_outside_f32_band(f[0], x, c, ri, rd, 0) == 0
+    assert oracle.mismatches_outside_f32_band(f[2], x, c, ri, rd, 1) == 0
+
+
 def test_errors_are_loud():
     x = _dev(np.zeros((4, 128)))
     with pytest.raises(ValueError):
