@@ -10,12 +10,16 @@ include/ic_hip.h).  Importing this package touches neither HIP nor the shared li
 """
 from .imagedesc import ImageDesc
 from .vq import vq, kmeans2
-from .clustering import kmeans_assign, kmeans_fit
+from .clustering import chisqr, intersection, kmeans_assign, kmeans_fit
 from .features import BagOfWords, SpatialBagOfWords, Vocabulary
-from .scene_functions import compute_spatial_features, compute_vocab_features
+from .scene_functions import (compute_spatial_features, compute_spatial_features_from_xml,
+                              compute_vocab_features)
 from .classifiers import KNNScikit
 from .robust_matching import RobustMatcher
+from .knn_training import KnnTrainer
 
 __all__ = ["ImageDesc", "vq", "kmeans2", "kmeans_assign", "kmeans_fit", "BagOfWords",
-           "SpatialBagOfWords", "Vocabulary", "compute_vocab_features", "compute_spatial_features", "KNNScikit", "RobustMatcher"]
+           "SpatialBagOfWords", "Vocabulary", "compute_vocab_features", "compute_spatial_features",
+           "compute_spatial_features_from_xml", "KNNScikit", "KnnTrainer", "RobustMatcher",
+           "intersection", "chisqr"]
 __version__ = "0.1.0"
