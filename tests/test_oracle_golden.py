@@ -153,3 +153,56 @@ def test_degenerate_shapes(n, k):
     assert d3.shape == (n, 3)
     if n:
         assert np.all(i3[:, k:] == -1) and np.all(np.isinf(d3[:, k:]))
+
+
+# ---- the restated RANSAC / homography model: known-answer checks ---------------------------------
+def _project(H, pts):
+    t = np.c_[pts, np.ones(len(pts))].dot(H.T)
+    return t[:, :2] / t[:, 2:]
+
+
+def test_homography_fit_recovers_a_known_map_and_error_rule():
+    from oracle import ransac_ref
+    rng = np.random.default_rng(0)
+    H = np.array([[0.8, -0.2, 31.0], [0.15, 1.1, -12.0], [2e-4, -1e-4, 1.0]])
+    src = rng.random((40, 2)) * 400
+    data = np.c_[src, _project(H, src)]
+    for n in (4, 5, 40):                                  # minimal and over-determined
+        fit = ransac_ref.HomographyModel.fit(data[:n])
+        assert np.abs(fit - H).max() <= 1e-7 * np.abs(H).max()
+    err = ransac_ref.HomographyModel.get_error(data, H)
+    assert err.shape == (40,) and err.max() < 1e-6
+    # the error is the Euclidean reprojection distance (plus the reference's epsilon quirk)
+    moved = data.copy()
+    moved[:, 2] += 3.0
+    moved[:, 3] -= 4.0
+    assert np.allclose(ransac_ref.HomographyModel.get_error(moved, H), 5.0, atol=1e-6)
+    # degenerate input (all source points equal) gives no model
+    same = np.c_[np.ones((6, 2)), rng.random((6, 2))]
+    assert ransac_ref.HomographyModel.fit(same) is None
+
+
+def test_ransac_restatement_semantics():
+    from oracle import ransac_ref
+    rng = np.random.RandomState(4)
+    H = np.array([[1.05, 0.02, -8.0], [-0.03, 0.97, 14.0], [1e-5, 3e-5, 1.0]])
+    src = rng.rand(80, 2) * 500
+    dst = _project(H, src) + rng.randn(80, 2) * 0.2
+    dst[50:] = rng.rand(30, 2) * 500                      # 30 outliers
+    data = np.c_[src, dst]
+    assert ransac_ref.ransac_num_iterations(100, 0.95, 0.5) == 46   # int(log(.05)/log(1-.5^4))
+    assert ransac_ref.ransac_num_iterations(10, 0.95, 0.5) == 10
+    info = {}
+    fit, mask, err = ransac_ref.ransac(data, ransac_ref.HomographyModel, 4, 100, 3.0, rng=rng,
+                                       info=info)
+    assert fit is not None and mask[:50].sum() >= 45 and mask[50:].sum() <= 1 and err < 1.0
+    assert 0 <= info["best_it"] < 46
+    # fewer than MIN_INLIERS_TH inliers, or a mean error above the threshold: rejected
+    few = data[np.r_[0:8, 50:80]]
+    fit, mask, err = ransac_ref.ransac(few, ransac_ref.HomographyModel, 4, 100, 3.0, rng=rng)
+    assert fit is None and mask.sum() == 0
+    # random_partition is np.random.shuffle of arange: first n and the rest
+    a, b = ransac_ref.random_partition(4, 10, np.random.RandomState(1))
+    ref = np.arange(10)
+    np.random.RandomState(1).shuffle(ref)
+    assert np.array_equal(a, ref[:4]) and np.array_equal(b, ref[4:])
