@@ -584,7 +584,7 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
 
 // ---------------------------------------------------------------------------------------------
 // Direct search: sum (x - c)^2 in float32 for every (row, codeword) pair, no norm expansion and
-// therefore no cancellation.  Ten times the work of the matrix-core kernel on the vector ALU; it
+// therefore no cancellation.  Twice the arithmetic of the matrix-core kernel (a subtraction and an FMA per component) plus the reads, four times its run time, on the vector ALU; it
 // exists as the on-device checker for sizes no CPU oracle can handle and for callers that want
 // distances free of the expansion's rounding.  16 rows per workgroup live in LDS (every lane
 // reads the same row element: a broadcast), every thread walks codewords t, t+256, ... keeping a

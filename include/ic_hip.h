@@ -100,7 +100,7 @@ int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int6
 
 /* Same contract as ic_assign_top2, computed by direct differences sum (x-c)^2 in float32 on the
  * vector ALU (what scipy's _vq.vq does for small inputs, model/features.py:1166) instead of the
- * norm expansion on the matrix cores: about ten times slower, free of the expansion's rounding.
+ * norm expansion on the matrix cores: about four times slower (78.9 ms against 18.6 ms for 1M x 10k), free of the expansion's rounding.
  * It is the on-device checker of the fast path at sizes no CPU oracle can handle. */
 int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                          int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,

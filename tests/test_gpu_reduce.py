@@ -189,7 +189,7 @@ def test_config2_full_size_properties():
     rd, ri = oracle.topk(xs, cb.cpu().numpy(), 2)
     must, bad, agree = oracle.check_indices(idx[:20000].cpu().numpy(), ri, rd, 0)
     assert bad == 0 and agree >= 0.9999
-    # (9) ALL rows against the direct search on the device (no norm expansion, ten times the
+    # (9) ALL rows against the direct search on the device (no norm expansion, four times the
     #     work): the nearest codeword must agree wherever the direct search separates the best two
     #     by more than 1e-5 relative, and the distances must agree to 1e-4
     e1, ed1, e2, ed2, _ = ops.assign_top2_exact(x, cb)
