@@ -287,8 +287,12 @@ def _assign_from_host_parts(parts, c, c_sqnorm, top2, ratio, want_dist, chunk_ro
             free[b].synchronize()
         futures, dst = [], 0
         for p, lo, hi in jobs:
-            futures.append(pool.submit(_copy_rows, stage_np[b][dst:dst + hi - lo], p[lo:hi]))
-            dst += hi - lo
+            # large pieces are cut so that every worker thread gets a share of the copy
+            step = max(4096, -(-(hi - lo) // GATHER_THREADS))
+            for sub in range(lo, hi, step):
+                top = min(hi, sub + step)
+                futures.append(pool.submit(_copy_rows, stage_np[b][dst:dst + top - sub], p[sub:top]))
+                dst += top - sub
         for f in futures:
             f.result()
         with torch.cuda.stream(side):
