@@ -473,3 +473,72 @@ def test_spatial_bag_of_words_end_to_end(backend):
     ref = oracle.compute_spatial_features(codes, kps, 24, 3, 160, 80)
     assert feats.shape == (4, 21 * 24) and np.array_equal(feats, ref)
     assert sbow._build_histogram([], []) == []
+
+
+# ---- argument handling side by side with the libraries the reference calls -------------------------
+def test_vq_and_kmeans2_reject_what_scipy_rejects(backend):
+    from scipy.cluster.vq import kmeans2 as sp_kmeans2, vq as sp_vq
+    rng = np.random.default_rng(0)
+    good_x = rng.random((20, 8)).astype(np.float32)
+    good_c = rng.random((5, 8))
+    nan_x = good_x.copy()
+    nan_x[3, 2] = np.nan
+    inf_c = good_c.copy()
+    inf_c[1, 1] = np.inf
+    cases = [
+        (good_x, good_c[:, :7]),            # feature mismatch
+        (good_x, good_c[0]),                # rank mismatch
+        (good_x[0], good_c),                # rank mismatch the other way
+        (nan_x, good_c),                    # NaN in the observations
+        (good_x, inf_c),                    # inf in the code book
+        (good_x.reshape(5, 4, 8), good_c),  # 3-D observations
+    ]
+    for obs, cb in cases:
+        with pytest.raises(Exception) as theirs:
+            sp_vq(obs, cb)
+        with pytest.raises(Exception) as ours:
+            vq(obs, cb, backend=backend)
+        assert type(ours.value) is type(theirs.value), (obs.shape, np.shape(cb))
+    # accepted by both: 1-D observations with a 1-D code book, empty observations
+    c1, d1 = sp_vq(good_x[:, 0], good_c[:, 0])
+    c2, d2 = vq(good_x[:, 0], good_c[:, 0], backend=backend)
+    assert np.array_equal(c1, c2) and np.allclose(d1, d2, rtol=1e-5)
+    for kwargs in (dict(minit="nope"), dict(missing="nope")):
+        with pytest.raises(Exception) as theirs:
+            sp_kmeans2(good_x.astype(np.float64), 3, **kwargs)
+        with pytest.raises(Exception) as ours:
+            kmeans2(good_x.astype(np.float64), 3, backend=backend, **kwargs)
+        assert type(ours.value) is type(theirs.value), kwargs
+    for k in (0, 21):                       # no clusters / more clusters than observations
+        with pytest.raises(Exception) as theirs:
+            sp_kmeans2(good_x.astype(np.float64), k, minit="points")
+        with pytest.raises(Exception) as ours:
+            kmeans2(good_x.astype(np.float64), k, minit="points", backend=backend)
+        assert type(ours.value) is type(theirs.value), k
+
+
+def test_knn_scikit_rejects_what_sklearn_rejects(backend):
+    from sklearn.neighbors import KNeighborsClassifier
+    rng = np.random.default_rng(1)
+    fit_x = rng.random((12, 6))
+    labels = list(range(12))
+    ref = KNeighborsClassifier(n_neighbors=3, algorithm="brute").fit(fit_x, labels)
+    knn = KNNScikit(3, backend=backend)
+    knn.train(fit_x, labels)
+    bad_calls = [
+        (rng.random((4, 6)), 13),           # more neighbours than fitted rows
+        (rng.random((4, 6)), 0),            # no neighbours
+        (rng.random((4, 5)), 2),            # feature mismatch
+        (rng.random(6), 2),                 # 1-D query
+    ]
+    for feats, k in bad_calls:
+        with pytest.raises(Exception) as theirs:
+            ref.kneighbors(feats, n_neighbors=k)
+        with pytest.raises(Exception) as ours:
+            knn.get_neighbors(feats, k)
+        assert type(ours.value) is type(theirs.value), (np.shape(feats), k)
+    with pytest.raises(ValueError):
+        KNNScikit(3, backend=backend).train(fit_x, labels[:-1])
+    d_ref, i_ref = ref.kneighbors(fit_x[:5], n_neighbors=3)
+    d, i = knn.get_neighbors(fit_x[:5], 3)
+    assert np.array_equal(i, i_ref) and np.allclose(d, d_ref, atol=1e-6)
