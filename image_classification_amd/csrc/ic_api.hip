@@ -527,17 +527,23 @@ int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t
   if (rows < 1) rows = 1;
   if (rows > m) rows = m;
   if (rows > 65535 * 64) rows = 65535 * 64;
-  int rc = ensure_ws(ctx, align_up((size_t)rows * (size_t)n * 8));
+  const int nch = ic::topk_chunks(rows, n, k);
+  const size_t o_pd = align_up((size_t)rows * (size_t)n * 8);
+  const size_t o_pi = o_pd + align_up((size_t)rows * nch * k * 8);
+  int rc = ensure_ws(ctx, o_pi + align_up((size_t)rows * nch * k * 4));
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
   double* dist = reinterpret_cast<double*>(ctx->ws);
+  double* part_d = reinterpret_cast<double*>(ctx->ws + o_pd);
+  int32_t* part_i = reinterpret_cast<int32_t*>(ctx->ws + o_pi);
   for (int64_t r0 = 0; r0 < m; r0 += rows) {
     const int64_t mr = m - r0 < rows ? m - r0 : rows;
     IC_HIP(ic::launch_pairdist(x + r0 * d, mr, c, n, d, metric, dist, s),
            "pairwise distance kernel");
-    IC_HIP(ic::launch_topk_rows(dist, mr, n, k, out_dist + r0 * k, out_idx + r0 * k, s),
-           "row top-k kernel");
+    IC_HIP(ic::launch_topk_rows(dist, mr, n, k, nch, part_d, part_i, out_dist + r0 * k,
+                                out_idx + r0 * k, s),
+           "row top-k kernels");
   }
   return finish_call(ctx, s);
 }

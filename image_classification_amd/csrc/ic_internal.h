@@ -94,8 +94,12 @@ hipError_t launch_centroid_finalize(const double* sums, const int64_t* counts, c
 // ---- ic_knn.hip ------------------------------------------------------------------------------
 hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n, int d, int metric,
                            double* out, hipStream_t s);
-hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, double* out_d,
-                            int32_t* out_i, hipStream_t s);
+// chunks a row is cut into for the top-k (1 = one workgroup per row); partial buffers hold
+// m * chunks * k entries
+int topk_chunks(int64_t m, int64_t n, int k);
+hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, int nch,
+                            double* part_d, int32_t* part_i, double* out_d, int32_t* out_i,
+                            hipStream_t s);
 
 // ---- ic_match.hip ----------------------------------------------------------------------------
 hipError_t launch_compact_matches(const uint8_t* mask, const int32_t* i1, const int64_t* row_off,

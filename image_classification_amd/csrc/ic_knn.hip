@@ -112,7 +112,7 @@ constexpr int kFewQ = 4;         // search rows per pass
 constexpr int kFewR = 2;         // index rows per wave
 constexpr int kFewFlush = 8;     // f32 partial sums are folded into float64 every 8 blocks
 
-template <int METRIC, bool VEC>
+template <int METRIC, bool VEC, int Q>
 __global__ __launch_bounds__(256) void k_pairdist_few(
     const float* __restrict__ x, int m0, int mq, const float* __restrict__ c, int64_t n, int d,
     double* __restrict__ out) {
@@ -122,22 +122,22 @@ __global__ __launch_bounds__(256) void k_pairdist_few(
   if (r0 >= n) return;
   constexpr int W = VEC ? 4 : 1;          // floats per lane per block
   const int block = 64 * W;
-  double acc[kFewQ][kFewR];
+  double acc[Q][kFewR];
 #pragma unroll
-  for (int q = 0; q < kFewQ; ++q)
+  for (int q = 0; q < Q; ++q)
 #pragma unroll
     for (int r = 0; r < kFewR; ++r) acc[q][r] = 0.0;
   const float* crow[kFewR];
 #pragma unroll
   for (int r = 0; r < kFewR; ++r) crow[r] = c + (r0 + r < n ? r0 + r : n - 1) * (int64_t)d;
-  const float* xrow[kFewQ];
+  const float* xrow[Q];
 #pragma unroll
-  for (int q = 0; q < kFewQ; ++q) xrow[q] = x + (int64_t)(m0 + (q < mq ? q : mq - 1)) * d;
+  for (int q = 0; q < Q; ++q) xrow[q] = x + (int64_t)(m0 + (q < mq ? q : mq - 1)) * d;
 
   for (int d0 = 0; d0 < d; d0 += block * kFewFlush) {
-    float part[kFewQ][kFewR];
+    float part[Q][kFewR];
 #pragma unroll
-    for (int q = 0; q < kFewQ; ++q)
+    for (int q = 0; q < Q; ++q)
 #pragma unroll
       for (int r = 0; r < kFewR; ++r) part[q][r] = 0.f;
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_pairdist_few(
       const int dd = d0 + u * block + lane * W;
       const bool ok = dd < d;               // with VEC, d % 4 == 0: a lane's four floats are all in or out
       const int di = ok ? dd : 0;
-      float cv[kFewR][W], xv[kFewQ][W];
+      float cv[kFewR][W], xv[Q][W];
 #pragma unroll
       for (int r = 0; r < kFewR; ++r) {
         if (VEC) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_pairdist_few(
         }
       }
 #pragma unroll
-      for (int q = 0; q < kFewQ; ++q) {
+      for (int q = 0; q < Q; ++q) {
         if (VEC) {
           const float4 t = *reinterpret_cast<const float4*>(xrow[q] + di);
           xv[q][0] = t.x; xv[q][1 % W] = t.y; xv[q][2 % W] = t.z; xv[q][3 % W] = t.w;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_pairdist_few(
         }
       }
 #pragma unroll
-      for (int q = 0; q < kFewQ; ++q)
+      for (int q = 0; q < Q; ++q)
 #pragma unroll
         for (int r = 0; r < kFewR; ++r) {
           float t = 0.f;
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(256) void k_pairdist_few(
         }
     }
 #pragma unroll
-    for (int q = 0; q < kFewQ; ++q)
+    for (int q = 0; q < Q; ++q)
 #pragma unroll
       for (int r = 0; r < kFewR; ++r) acc[q][r] += (double)part[q][r];
   }
 #pragma unroll
-  for (int q = 0; q < kFewQ; ++q)
+  for (int q = 0; q < Q; ++q)
 #pragma unroll
     for (int r = 0; r < kFewR; ++r) {
       double v = acc[q][r];
@@ -200,24 +200,26 @@ __device__ __forceinline__ bool pair_less(double d, int32_t i, double e, int32_t
   return d < e || (d == e && i < j);
 }
 
-// dist [m][n] -> the k smallest (distance, index) pairs of every row, ascending.
-__global__ __launch_bounds__(kTopkThreads) void k_topk_rows(
-    const double* __restrict__ dist, int64_t n, int k, double* __restrict__ out_d,
-    int32_t* __restrict__ out_i) {
+// The k smallest (value, index) pairs of vals[0 .. len), ascending, by one workgroup: k rounds of
+// "smallest pair above the previous one".  Candidate j has index idx ? idx[j] : j0 + j.  Rounds
+// that find nothing (fewer than k candidates) write +inf / 0x7fffffff.
+__device__ __forceinline__ void topk_scan(const double* __restrict__ vals,
+                                          const int32_t* __restrict__ idx, int64_t j0, int64_t len,
+                                          int k, double* __restrict__ out_d,
+                                          int32_t* __restrict__ out_i, bool final_pass) {
   __shared__ double sd[kTopkThreads / 64];
   __shared__ int32_t si[kTopkThreads / 64];
   __shared__ double last_d;
   __shared__ int32_t last_i;
-  const double* row = dist + (int64_t)blockIdx.x * n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double prev_d = -__builtin_inf();
   int32_t prev_i = -1;
   for (int r = 0; r < k; ++r) {
     double best_d = __builtin_inf();
     int32_t best_i = 0x7fffffff;
-    for (int64_t j = threadIdx.x; j < n; j += kTopkThreads) {
-      const double v = row[j];
-      const int32_t ji = (int32_t)j;
+    for (int64_t j = threadIdx.x; j < len; j += kTopkThreads) {
+      const double v = vals[j];
+      const int32_t ji = idx ? idx[j] : (int32_t)(j0 + j);
       const bool above = pair_less(prev_d, prev_i, v, ji);
       const bool better = pair_less(v, ji, best_d, best_i);
       if (above && better) {
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_rows(
         }
       last_d = bd;
       last_i = bi;
-      out_d[(int64_t)blockIdx.x * k + r] = bd;
-      out_i[(int64_t)blockIdx.x * k + r] = bi == 0x7fffffff ? -1 : bi;
+      out_d[r] = bd;
+      out_i[r] = (final_pass && bi == 0x7fffffff) ? -1 : bi;
     }
     __syncthreads();
     prev_d = last_d;
@@ -258,18 +260,56 @@ __global__ __launch_bounds__(kTopkThreads) void k_topk_rows(
   }
 }
 
+// dist [m][n] -> the k smallest (distance, index) pairs of every row, ascending.
+__global__ __launch_bounds__(kTopkThreads) void k_topk_rows(
+    const double* __restrict__ dist, int64_t n, int k, double* __restrict__ out_d,
+    int32_t* __restrict__ out_i) {
+  topk_scan(dist + (int64_t)blockIdx.x * n, nullptr, 0, n, k, out_d + (int64_t)blockIdx.x * k,
+            out_i + (int64_t)blockIdx.x * k, true);
+}
+
+// Few search rows over a long index: the row is cut into gridDim.y chunks whose local top-k are
+// merged by k_topk_merge, so that one row is not left to a single workgroup.
+__global__ __launch_bounds__(kTopkThreads) void k_topk_chunks(
+    const double* __restrict__ dist, int64_t n, int k, double* __restrict__ part_d,
+    int32_t* __restrict__ part_i) {
+  const int64_t nch = gridDim.y;
+  const int64_t c0 = n * blockIdx.y / nch, c1 = n * (blockIdx.y + 1) / nch;
+  const int64_t o = ((int64_t)blockIdx.x * nch + blockIdx.y) * k;
+  topk_scan(dist + (int64_t)blockIdx.x * n + c0, nullptr, c0, c1 - c0, k, part_d + o, part_i + o,
+            false);
+}
+
+__global__ __launch_bounds__(kTopkThreads) void k_topk_merge(
+    const double* __restrict__ part_d, const int32_t* __restrict__ part_i, int nch, int k,
+    double* __restrict__ out_d, int32_t* __restrict__ out_i) {
+  const int64_t o = (int64_t)blockIdx.x * nch * k;
+  topk_scan(part_d + o, part_i + o, 0, (int64_t)nch * k, k, out_d + (int64_t)blockIdx.x * k,
+            out_i + (int64_t)blockIdx.x * k, true);
+}
+
 }  // namespace
 
+template <int METRIC, int Q>
+static void launch_few_q(const float* x, int m0, int mq, const float* c, int64_t n, int d,
+                         double* out, hipStream_t s) {
+  const dim3 grid((unsigned)((n + 4 * kFewR - 1) / (4 * kFewR)));
+  if (d % 4 == 0)
+    hipLaunchKernelGGL((k_pairdist_few<METRIC, true, Q>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
+  else
+    hipLaunchKernelGGL((k_pairdist_few<METRIC, false, Q>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
+}
+
+// up to kFewQ search rows per pass over the index; a single search row gets its own instantiation
+// so that it pays for one row's arithmetic only and stays bound by reading the index
 template <int METRIC>
 static void launch_few(const float* x, int64_t m, const float* c, int64_t n, int d, double* out,
                        hipStream_t s) {
-  const dim3 grid((unsigned)((n + 4 * kFewR - 1) / (4 * kFewR)));
   for (int m0 = 0; m0 < (int)m; m0 += kFewQ) {
     const int mq = (int)m - m0 < kFewQ ? (int)m - m0 : kFewQ;
-    if (d % 4 == 0)
-      hipLaunchKernelGGL((k_pairdist_few<METRIC, true>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
-    else
-      hipLaunchKernelGGL((k_pairdist_few<METRIC, false>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
+    if (mq == 1) launch_few_q<METRIC, 1>(x, m0, mq, c, n, d, out, s);
+    else if (mq == 2) launch_few_q<METRIC, 2>(x, m0, mq, c, n, d, out, s);
+    else launch_few_q<METRIC, kFewQ>(x, m0, mq, c, n, d, out, s);
   }
 }
 
@@ -310,10 +350,27 @@ hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n,
   return hipGetLastError();
 }
 
-hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, double* out_d,
-                            int32_t* out_i, hipStream_t s) {
-  hipLaunchKernelGGL(k_topk_rows, dim3((unsigned)m), dim3(kTopkThreads), 0, s, dist, n, k, out_d,
-                     out_i);
+int topk_chunks(int64_t m, int64_t n, int k) {
+  // chunking pays when the rows alone cannot fill the machine and a row is long
+  if (m >= 128 || n < 16384) return 1;
+  int64_t nch = 512 / m;
+  if (nch > n / 4096) nch = n / 4096;
+  if (nch > n / (2 * (int64_t)k)) nch = n / (2 * (int64_t)k);
+  return nch < 2 ? 1 : (int)nch;
+}
+
+hipError_t launch_topk_rows(const double* dist, int64_t m, int64_t n, int k, int nch,
+                            double* part_d, int32_t* part_i, double* out_d, int32_t* out_i,
+                            hipStream_t s) {
+  if (nch <= 1) {
+    hipLaunchKernelGGL(k_topk_rows, dim3((unsigned)m), dim3(kTopkThreads), 0, s, dist, n, k, out_d,
+                       out_i);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_topk_chunks, dim3((unsigned)m, (unsigned)nch), dim3(kTopkThreads), 0, s,
+                     dist, n, k, part_d, part_i);
+  hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)m), dim3(kTopkThreads), 0, s, part_d, part_i, nch,
+                     k, out_d, out_i);
   return hipGetLastError();
 }
 

@@ -93,6 +93,25 @@ def test_knn_rows_matches_descriptor_search_on_128d():
                               d1.cpu().numpy()[agree.cpu().numpy()]) <= REL
 
 
+def test_knn_rows_long_index_few_queries():
+    # one or two search rows over a long index: the row top-k is cut into chunks and merged
+    rng = np.random.default_rng(23)
+    c = _hists(rng, 40_000, 64)
+    c[30_000] = c[5]                                     # a tie across chunks: lowest index first
+    for m, k in ((1, 3), (2, 7), (5, 1)):
+        x = _hists(rng, m, 64)
+        x[0] = c[5]
+        dist, idx = ops.knn_rows(_dev(x), _dev(c), k, "manhattan")
+        rd, ri = oracle.kneighbors_metric(c, x, k, "manhattan")
+        # count histograms tie in exact arithmetic; float32 terms order such ties differently
+        assert oracle.check_close(dist.cpu().numpy(), rd, abs_floor=1e-9) <= REL
+        clear = np.ones_like(ri, dtype=bool)
+        clear[:, 1:] &= np.diff(rd, axis=1) > 1e-6 * rd[:, 1:]
+        clear[:, :-1] &= np.diff(rd, axis=1) > 1e-6 * rd[:, 1:]
+        assert np.array_equal(idx.cpu().numpy()[clear], ri[clear])
+        assert idx[0, 0] == 5 and (k < 2 or idx[0, 1] == 30_000)
+
+
 def test_knn_argument_errors():
     x = _dev(np.zeros((4, 10), np.float32))
     c = _dev(np.zeros((3, 10), np.float32))
