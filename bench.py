@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the descriptor -> codeword assignment path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload bow|knn|kmeans|video]
+    python bench.py --gpus N --steps K --warmup W [--workload bow|knn|kmeans|video|logo|histknn]
 
 One step = one pass of the hot path over one batch of synthetic descriptors resident in HBM.
 The default workload is BASELINE config 2, "BoW quantisation + per-image L2-normalised histograms:
@@ -19,6 +19,8 @@ sizing cases run by hand, not the line the driver records):
   logo    config 3 in the reference's own direction: the 2M descriptors of 20 000 logo images are
           searched in the 4k-descriptor index of the query (top-2 + ratio test), matches are
           compacted per logo and verified by the batched homography RANSAC
+  histknn the logo k-NN classifier's search: one query histogram vs 100 000 index histograms of
+          10k bins, manhattan, 2 neighbours (HBM-bound: its roofline counts the index bytes)
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA distance /
 top-2 kernel): algorithmic FLOPs per launch = 2 * N * K * D, divided by its average duration
@@ -42,6 +44,7 @@ if ROOT not in sys.path:
 
 DIM = 128
 FP32_MFMA_PEAK_TFLOPS = 157.3  # 256 CU x 256 FLOP/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
     "bow": dict(rows=1_000_000, k=10_000, images=1000, norm="l2",
@@ -60,6 +63,9 @@ WORKLOADS = {
     "knn": dict(rows=4000, k=2_000_000,
                 name="BASELINE config 3: 4k query descriptors vs 2M-descriptor index (split over "
                      "ranks), top-2 + ratio test, all-gather + merge"),
+    "histknn": dict(rows=100_000, k=10_000,
+                    name="histogram-space 2-NN (the logo k-NN classifier): one query histogram vs "
+                         "100 000 L1-normalised 10k-bin histograms, manhattan, float64 distances"),
 }
 
 
@@ -237,6 +243,19 @@ def main():
             out_off, mq, mi, pts = ops.compact_matches(mask, i1, row_off, kp_q, kp_rows)
             res = ops.ransac_homography(pts, out_off, n_iter, 3.0, None, 1, 10, True)
             return res[1], out_off
+    elif args.workload == "histknn":
+        g = torch.Generator(device=dev)
+        g.manual_seed(21 + rank)
+        index = torch.empty((n_rows, k_words), dtype=torch.float32, device=dev)
+        for r0 in range(0, n_rows, 10_000):   # sparse count histograms, about 1000 words per image
+            cnt = torch.poisson(torch.full((min(10_000, n_rows - r0), k_words), 0.1, device=dev),
+                                generator=g)
+            index[r0:r0 + cnt.shape[0]] = cnt / cnt.sum(1, keepdim=True).clamp_(min=1)
+        query = index[n_rows // 2:n_rows // 2 + 1].clone()
+        bytes_per_launch = float(n_rows) * k_words * 4
+
+        def step():
+            return ops.knn_rows(query, index, 2, "manhattan")
     else:  # knn: the index is split over ranks, the queries are replicated
         bounds = D.shard_bounds(k_words, world)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
@@ -293,13 +312,25 @@ def main():
         props = torch.cuda.get_device_properties(dev)
         value = world * units_per_step * args.steps / dt_max
         avg_kernel_s = kern_ms / max(1, launches) / 1e3
-        achieved = flops_per_launch / avg_kernel_s / 1e12
         is_pairs = args.workload == "knn"
+        is_hist = args.workload == "histknn"
+        if is_hist:
+            achieved = bytes_per_launch / avg_kernel_s / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_pairdist_few", "avg_kernel_ms": avg_kernel_s * 1e3,
+                        "bytes_per_launch": bytes_per_launch}
+        else:
+            achieved = flops_per_launch / avg_kernel_s / 1e12
+        metric, unit = ("descriptor->codeword assignments/sec", "assignments/s")
+        if is_pairs:
+            metric, unit = ("query-index descriptor pairs examined/sec", "pairs/s")
+        if is_hist:
+            metric, unit = ("index histograms compared/sec", "histograms/s")
         out = {
-            "metric": "descriptor->codeword assignments/sec" if not is_pairs
-                      else "query-index descriptor pairs examined/sec",
+            "metric": metric,
             "value": value,
-            "unit": "assignments/s" if not is_pairs else "pairs/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -311,13 +342,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": w["name"], "rows_per_gpu": n_rows,
                        "codebook": k_words if not is_pairs else int(flops_per_launch / (2.0 * n_rows * DIM)),
-                       "dim": DIM,
+                       "dim": k_words if is_hist else DIM,
                        "parallelism": {"bow": "rows sharded, no collective",
                                        "video": "frames sharded, no collective",
                                        "logo": "logo images sharded, no collective",
                                        "kmeans": "rows sharded, RCCL all-reduce of sums+counts per iteration",
+                                       "histknn": "replicas (index rows would shard, top-k merge)",
                                        "knn": "index sharded, RCCL all-gather + top-2 merge"}[args.workload]},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": roofline if is_hist else {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": measured_traffic(args.workload),
                          "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,

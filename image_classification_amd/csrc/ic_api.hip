@@ -115,6 +115,26 @@ int finish_call(Ctx* c, hipStream_t s) {
   return IC_OK;
 }
 
+// When the handle is profiling: records the start event of a dominant-kernel launch on `s` and
+// hands back the stop event to record after it (null otherwise).
+int profile_open(Ctx* c, hipStream_t s, hipEvent_t* stop) {
+  *stop = nullptr;
+  if (!c->profiling) return IC_OK;
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return fail_hip(e, "hipEventCreate");
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) return fail_hip(e, "hipEventCreate");
+    c->ev_pool.emplace_back(a, b);
+  }
+  hipError_t e = hipEventRecord(c->ev_pool[c->ev_used].first, s);
+  if (e != hipSuccess) return fail_hip(e, "hipEventRecord");
+  *stop = c->ev_pool[c->ev_used].second;
+  c->ev_used++;
+  return IC_OK;
+}
+
 #define IC_HIP(call, what)                            \
   do {                                                \
     hipError_t e__ = (call);                          \
@@ -168,19 +188,9 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     cs = cp;
   }
   IC_HIP(ic::launch_codebook_norms(cs, k, kpad, c_sqnorm, cn, s), "codebook norms");
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (ctx->profiling) {
-    if (ctx->ev_used == ctx->ev_pool.size()) {
-      hipEvent_t a, b;
-      IC_HIP(hipEventCreate(&a), "hipEventCreate");
-      IC_HIP(hipEventCreate(&b), "hipEventCreate");
-      ctx->ev_pool.emplace_back(a, b);
-    }
-    ev0 = ctx->ev_pool[ctx->ev_used].first;
-    ev1 = ctx->ev_pool[ctx->ev_used].second;
-    ctx->ev_used++;
-    IC_HIP(hipEventRecord(ev0, s), "hipEventRecord");
-  }
+  hipEvent_t ev1 = nullptr;
+  int prc = profile_open(ctx, s, &ev1);
+  if (prc) return prc;
   float* thr = nullptr;
   if (hint) {
     thr = reinterpret_cast<float*>(ctx->ws + o_thr);
@@ -539,8 +549,12 @@ int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t
   int32_t* part_i = reinterpret_cast<int32_t*>(ctx->ws + o_pi);
   for (int64_t r0 = 0; r0 < m; r0 += rows) {
     const int64_t mr = m - r0 < rows ? m - r0 : rows;
+    hipEvent_t ev1 = nullptr;
+    rc = profile_open(ctx, s, &ev1);
+    if (rc) return rc;
     IC_HIP(ic::launch_pairdist(x + r0 * d, mr, c, n, d, metric, dist, s),
            "pairwise distance kernel");
+    if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
     IC_HIP(ic::launch_topk_rows(dist, mr, n, k, nch, part_d, part_i, out_dist + r0 * k,
                                 out_idx + r0 * k, s),
            "row top-k kernels");

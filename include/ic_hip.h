@@ -61,7 +61,8 @@ int ic_destroy(void* handle);
 const char* ic_last_error(void* handle); /* handle may be NULL: error of the last failed ic_create */
 
 /* Timing of the distance kernel with HIP events recorded on the caller's stream, one pair per
- * ic_assign_* call between begin and end.  ic_profile_end waits for those events and returns
+ * ic_assign_* call (the descriptor search kernel) or per ic_knn_rows batch (the pairwise distance
+ * kernel) between begin and end.  ic_profile_end waits for those events and returns
  * the summed kernel time in milliseconds and the number of launches.  No counterpart in the
  * reference; used by bench.py for the roofline figure. */
 int ic_profile_begin(void* handle);
