@@ -93,8 +93,20 @@ def cpu_baseline(x_sample, codebook, per_image, norm):
             one_core = ns1 / (time.perf_counter() - t1)
     except Exception:
         pass
+    scipy_value = scipy_agree = None
+    try:   # the library call the reference itself makes (model/features.py:1166), where installed
+        from scipy.cluster.vq import vq as scipy_vq
+        ns2 = max(per_image, x_sample.shape[0] // 10 // per_image * per_image)
+        xs, cs = x_sample[:ns2].astype(np.float64), codebook.astype(np.float64)
+        t2 = time.perf_counter()
+        sc_code, _ = scipy_vq(xs, cs)
+        scipy_value = ns2 / (time.perf_counter() - t2)
+        scipy_agree = float(np.mean(sc_code == code[:ns2]))
+    except ImportError:
+        pass
     return {"value": x_sample.shape[0] / dt, "unit": "assignments/s", "cores": int(cores),
-            "kind": "port", "one_core_value": one_core,
+            "kind": "port", "one_core_value": one_core, "scipy_vq_value": scipy_value,
+            "scipy_vq_agreement_with_port": scipy_agree,
             "sample": "%d rows of the workload (same codebook; float64 numpy GEMM + argmin + "
                       "np.histogram), %.1f s" % (x_sample.shape[0], dt)}, code
 
@@ -128,8 +140,8 @@ def cpu_baseline_logo(x, kp_rows, q, kp_q, per, n_logos, n_iter, gpu_inliers, gp
             "agreement_with_gpu": float(np.mean(gpu_ok == np.asarray(accepted)))}
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the distance kernel from the newest committed PMC summary of this
+def measured_traffic(workload, kernel="k_top2_partial"):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary of this
     workload (profiles/rNN_<workload>_traffic.json)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % workload)))
     if not files:
@@ -137,7 +149,7 @@ def measured_traffic(workload):
     try:
         data = json.load(open(files[-1]))
         for name, rec in data.items():
-            if "k_top2_partial" in name:
+            if kernel in name:
                 return float(rec["hbm_bytes_per_launch"])
     except Exception:
         return None
@@ -317,7 +329,8 @@ def main():
         if is_hist:
             achieved = bytes_per_launch / avg_kernel_s / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": measured_traffic(args.workload, "k_pairdist_few"),
                         "kernel": "k_pairdist_few", "avg_kernel_ms": avg_kernel_s * 1e3,
                         "bytes_per_launch": bytes_per_launch}
         else:

@@ -19,7 +19,7 @@ def mean_per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter or "ic::" not in r["Kernel_Name"]:
             continue
-        name = r["Kernel_Name"].replace("void ", "")
+        name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
         name = name[:name.find("(")] if "(" in name else name
         a = agg.setdefault(name, [0, 0.0])
         a[0] += 1
