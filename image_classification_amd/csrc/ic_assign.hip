@@ -304,6 +304,55 @@ __device__ __forceinline__ void tile_epilogue_skip2(const f32x16 (&acc)[XT], Top
   }
 }
 
+// The same with a tighter gate.  The two lanes that hold one descriptor (lane and lane + 32) rank
+// different halves of every tile's codewords, and each lane's own second best is a loose bound for
+// the descriptor: once per stage the pair exchanges its lists, and a candidate is ranked only when
+// it is below min(own second best, second best of the pair's four entries).  The pair's value is
+// raised by two units in the last place first, so a candidate that ties it is still ranked and the
+// final merge by (value, index) sees it.  About half as many candidates get past the gate.
+template <int XT>
+__device__ __forceinline__ void tile_epilogue_skip3(const f32x16 (&acc)[XT], Top2 (&st)[XT],
+                                                    float (&gate)[XT], int encbase) {
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    const f32x16& a = acc[xt];
+    const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
+                          min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
+                          __builtin_inff());
+    if (__builtin_amdgcn_ballot_w64(m < gate[xt]) != 0) {
+      float d1 = st[xt].d1, d2 = st[xt].d2, g = gate[xt];
+      int l1 = -1, l2 = -2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
+          // a lane whose value is below its own second best but not below its gate ranks it too:
+          // needless, never wrong
+          top2_update(d1, d2, l1, l2, a[r], r);
+          g = __builtin_fminf(g, d2);
+        }
+      const int o1 = st[xt].i1, o2 = st[xt].i2;
+      st[xt].d1 = d1;
+      st[xt].d2 = d2;
+      st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
+      st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
+      gate[xt] = g;
+    }
+  }
+}
+
+template <int XT>
+__device__ __forceinline__ void sync_gate(const Top2 (&st)[XT], float (&gate)[XT]) {
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
+    const float od1 = __shfl_xor(st[xt].d1, 32);
+    const float od2 = __shfl_xor(st[xt].d2, 32);
+    // second smallest of {d1, d2, od1, od2} given d1 <= d2 and od1 <= od2
+    float s2 = __builtin_fminf(__builtin_fmaxf(st[xt].d1, od1), __builtin_fminf(st[xt].d2, od2));
+    s2 = __builtin_fmaf(__builtin_fmaxf(__builtin_fabsf(s2), 1e-30f), 0x1p-22f, s2);
+    gate[xt] = __builtin_fminf(st[xt].d2, s2);
+  }
+}
+
 template <int XT>
 __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st)[XT], int encbase) {
 #pragma unroll
@@ -358,6 +407,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   }
 
   Top2 best[XT];
+  float gate[XT];
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
     // with a caller-supplied bound only candidates below it are ranked at all (index -1 = none)
@@ -370,6 +420,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     best[xt].d2 = start;
     best[xt].i1 = -1;
     best[xt].i2 = -1;
+    gate[xt] = start;
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -391,10 +442,12 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
+        if constexpr (SKIP == 3) sync_gate<XT>(best, gate);
       }
       if (live) {
         const int encbase = (st * kTilesPerStage + t) * 16;
-        if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, encbase);
+        if constexpr (SKIP == 3) tile_epilogue_skip3<XT>(acc, best, gate, encbase);
+        else if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, encbase);
         else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, encbase);
         else tile_epilogue<XT>(acc, best, encbase);
       }
@@ -432,13 +485,15 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
   const int64_t stages = (k + kStageK - 1) / kStageK;
   const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
   // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
-  // candidate, 1 = skip tiles no lane can improve, 2 (default) = also skip registers
+  // candidate, 1 = skip tiles no lane can improve, 2 = also skip registers, 3 (default) = the
+  // same against the bound the two lanes of a descriptor share
   static const int variant = [] {
     const char* v = getenv("IC_AMD_VARIANT");
-    return v ? atoi(v) : 2;
+    return v ? atoi(v) : 3;
   }();
   auto kern = variant == 0 ? k_top2_partial<kXT, kNW, 0>
-              : variant == 1 ? k_top2_partial<kXT, kNW, 1> : k_top2_partial<kXT, kNW, 2>;
+              : variant == 1 ? k_top2_partial<kXT, kNW, 1>
+              : variant == 3 ? k_top2_partial<kXT, kNW, 3> : k_top2_partial<kXT, kNW, 2>;
   const int lds = 2 * kStageBytes;
   // per device and cheap, so it is simply repeated on every call
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

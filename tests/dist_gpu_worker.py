@@ -17,6 +17,9 @@ from image_classification_amd.synthetic import sift_like  # noqa: E402
 
 
 def main():
+    # a rank stuck in a collective or a kernel ends itself with a traceback instead of hanging
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)

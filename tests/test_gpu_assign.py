@@ -97,6 +97,31 @@ def test_ties_lowest_index_wins():
     assert np.all(d1 == 0) and np.all(d2 == 0)
 
 
+@pytest.mark.parametrize("copies,stride", [(4, 1024), (3, 700), (2, 2052)])
+def test_exact_ties_across_many_stages(copies, stride):
+    # small-integer data (every product and sum exact in float32) and a codebook repeated several
+    # times: every candidate ties exactly with copies of itself that sit many 128-codeword stages
+    # later and, for strides that are not multiples of 8, in the other half of a tile's rows.
+    # The two best must be the two lowest-numbered copies of the nearest codeword.
+    rng = np.random.default_rng(copies * 10 + stride)
+    base = rng.integers(0, 4, size=(stride, 128)).astype(np.float32)
+    c = np.concatenate([base] * copies)
+    x = rng.integers(0, 4, size=(3000, 128)).astype(np.float32)
+    x[:stride][:500] = base[:500]   # exact hits too
+    i1, d1, i2, d2, _ = _run_top2(x, c)
+    # exact integer reference; a stable sort keeps the lowest index among equal distances
+    xi, ci = x.astype(np.int64), c.astype(np.int64)
+    sq = (xi * xi).sum(1)[:, None] - 2 * (xi @ ci.T) + (ci * ci).sum(1)[None, :]
+    ri = np.argsort(sq, axis=1, kind="stable")[:, :2]
+    rd = np.sqrt(np.take_along_axis(sq, ri, 1).astype(np.float32))
+    assert np.array_equal(i1, ri[:, 0])
+    assert np.array_equal(i2, ri[:, 1])
+    assert np.array_equal(d1, rd[:, 0])
+    assert np.array_equal(d2, rd[:, 1])
+    idx, _ = ops.assign_top1(_dev(x), _dev(c))
+    assert np.array_equal(idx.cpu().numpy(), ri[:, 0])
+
+
 @pytest.mark.parametrize("d", [64, 36, 100, 1])
 def test_other_dimensions_are_zero_padded(d):
     rng = np.random.default_rng(d)
