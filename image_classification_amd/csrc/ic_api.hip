@@ -188,14 +188,14 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     cs = cp;
   }
   IC_HIP(ic::launch_codebook_norms(cs, k, kpad, c_sqnorm, cn, s), "codebook norms");
-  hipEvent_t ev1 = nullptr;
-  int prc = profile_open(ctx, s, &ev1);
-  if (prc) return prc;
   float* thr = nullptr;
   if (hint) {
     thr = reinterpret_cast<float*>(ctx->ws + o_thr);
     IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, cn, hint, thr, s), "hint threshold kernel");
   }
+  hipEvent_t ev1 = nullptr;
+  rc = profile_open(ctx, s, &ev1);
+  if (rc) return rc;
   IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, plan, thr, part, s), "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   IC_HIP(ic::launch_rescore(xs, n, cs, part, plan, i1, d1, i2, d2, ratio, mask, rec, s),
