@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_two_ranks.py: two ranks share the one GPU of the test box and talk
+"""Worker of tests/test_zy_two_ranks_gpu.py: two ranks share the one GPU of the test box and talk
 over gloo (RCCL refuses two ranks on one device), so the sharded code paths run with the real
 kernels.  Every sharded result is compared with the unsharded run on the same device."""
 import os
