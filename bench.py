@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bow")
+    ap.add_argument("--codebook", type=int, default=0,
+                    help="override the workload's codebook size (bow / video / kmeans)")
+    ap.add_argument("--norm", default="", help="override the histogram norm (bow / video)")
     ap.add_argument("--cpu-sample", type=int, default=400_000,
                     help="rows of the workload the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
@@ -197,7 +200,13 @@ def main():
     from image_classification_amd.backend import HipBackend
     from image_classification_amd.synthetic import image_offsets, sift_like_device
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.codebook > 0:
+        w["k"] = args.codebook
+        w["name"] += " [codebook overridden: %d]" % args.codebook
+    if args.norm:
+        w["norm"] = args.norm
+        w["name"] += " [norm overridden: %s]" % args.norm
     backend = HipBackend(dev)
     n_rows, k_words = w["rows"], w["k"]
     flops_per_launch = None

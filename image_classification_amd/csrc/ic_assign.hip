@@ -11,8 +11,10 @@
 //   * MFMA v_mfma_f32_32x32x2_f32 with A = codeword tile (32 codewords, from LDS) and B = 32
 //     descriptors (registers).  The 32x32 result then has one DESCRIPTOR per lane and 16 CODEWORDS
 //     in that lane's registers, so the running top-2 of a descriptor never leaves its lane.
-//   * the contraction index is permuted: MFMA step s of lane half h multiplies component
-//     d = 64*h + s.  A lane therefore reads 256 contiguous bytes of "its" row for both operands.
+//   * the contraction index is permuted: lane half h multiplies the components of the even
+//     (h = 0) or odd (h = 1) 16-byte chunks of "its" row, for both operands.  The two lanes of a
+//     descriptor then fetch neighbouring chunks, so a load instruction touches 32 cache lines,
+//     not 64.
 //   * a wave keeps XT tiles of 32 descriptors (pre-scaled by -2) in registers for the whole sweep
 //     over the codebook; the accumulator is initialised with |c|^2, so the MFMA chain leaves
 //     |c|^2 - 2 x.c directly (|x|^2 is constant per row and cannot change the argmin).
@@ -36,25 +38,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTileK = 32;                          // codewords per MFMA tile
 constexpr int kRowBytes = kD * 4 + 16;              // 528: one 16-byte pad chunk per codeword row
 constexpr int kRowChunks = kRowBytes / 16;          // 33
-constexpr int kStageTileBytes = kStageK * kRowBytes;  // 67584 = 66 wave-instructions of 1 KiB
-constexpr int kStageGlds = kStageTileBytes / 1024;  // 33 per 64 codewords
-constexpr int kTilesPerStage = kStageK / kTileK;
-constexpr int kStageBytes = kStageTileBytes + kStageK * 4;  // + the stage's squared norms
-static_assert(kStageTileBytes % 1024 == 0, "a stage must be a whole number of 1 KiB pieces");
-static_assert(kStageGlds * 64 <= 8448, "issue_stage divides by 33 with a multiply-shift that is "
-                                       "exact only below 8448");
-static_assert(kStageK % 64 == 0, "the stage's norms are fetched 64 at a time");
-static_assert(kStageBytes % 16 == 0, "stage buffers must stay 16-byte aligned");
+// Sizes of one pipeline stage of SK codewords in LDS.
+template <int SK>
+struct Stage {
+  static constexpr int kTileBytes = SK * kRowBytes;      // 1 KiB = one wave-instruction of 16 B lanes
+  static constexpr int kGlds = kTileBytes / 1024;        // 33 per 64 codewords
+  static constexpr int kTiles = SK / kTileK;
+  static constexpr int kBytes = kTileBytes + SK * 4;     // + the stage's squared norms
+  static_assert(kTileBytes % 1024 == 0, "a stage must be a whole number of 1 KiB pieces");
+  static_assert(kGlds * 64 <= 8448, "issue_stage divides by 33 with a multiply-shift that is "
+                                    "exact only below 8448");
+  static_assert(SK % 64 == 0, "the stage's norms are fetched 64 at a time");
+  static_assert(kBytes % 16 == 0, "stage buffers must stay 16-byte aligned");
+  static_assert(kStageK % SK == 0, "the padded norms must cover whole stages");
+};
 
-// Geometry of the shipped instantiation: 8 waves (two per SIMD: LDS-read latency, barriers and the
-// 18 wait states between an MFMA and a vector read of its result are covered by the partner
-// wave), each holding 2 x 32 descriptors; 190 VGPRs, no spills.  Four waves holding 4 x 32
-// descriptors each (one wave per SIMD) made hipcc spill 170+ registers and was dropped.
+// Two geometries, both with two waves per SIMD (LDS-read latency, barriers and the 18 wait states
+// between an MFMA and a vector read of its result are covered by the partner wave), each wave
+// holding 2 x 32 descriptors; 190 VGPRs, no spills.  (Four waves holding 4 x 32 descriptors each,
+// one wave per SIMD, made hipcc spill 170+ registers and was dropped.)
+//   large: one workgroup of 8 waves per CU, stages of 128 codewords (136 KB of LDS);
+//   small: two workgroups of 4 waves per CU, stages of 64 codewords (68 KB each).  A workgroup
+//          spends about 10 us loading its rows and first stages before it multiplies; with two
+//          independent workgroups on a CU one of them multiplies meanwhile.  That pays while the
+//          scan is short (measured: 64 -> 70 % of peak at 256 codewords, 77.6 -> 80 % at 1000,
+//          equal at 2000, -0.7 points at 10 000 where the extra barriers and codebook reads cost
+//          more than the hidden prologue).
 constexpr int kXT = 2;
-constexpr int kNW = 8;
-constexpr int kRowsPerWg = kXT * kNW * 32;  // 512
-
-int assign_rows_per_wg() { return kRowsPerWg; }
+constexpr int kSmallCodebook = 2048;   // below this the small geometry is used
 
 // K-split that finishes `row_tiles` row tiles soonest on `num_cus` workgroup slots.
 static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
@@ -81,8 +92,18 @@ static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
 // its top-2, so ranking gets cheaper, and X is read once); only the row tiles of the last, partly
 // filled round are split along K so that their pieces spread over all CUs.
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
-  const int64_t stages = (k + kStageK - 1) / kStageK;
-  p->row_tiles = (n + kRowsPerWg - 1) / kRowsPerWg;
+  // IC_AMD_GEOMETRY forces a geometry (1 = small, 2 = large; tuning aid)
+  static const int geom = [] {
+    const char* v = getenv("IC_AMD_GEOMETRY");
+    return v ? atoi(v) : 0;
+  }();
+  const bool small = geom == 1 || (geom != 2 && k < kSmallCodebook);
+  p->waves = small ? 4 : 8;
+  p->stage_k = small ? 64 : 128;
+  p->rows_per_wg = kXT * p->waves * 32;
+  const int slots = num_cus * (8 / p->waves);  // workgroups resident at once
+  const int64_t stages = (k + p->stage_k - 1) / p->stage_k;
+  p->row_tiles = (n + p->rows_per_wg - 1) / p->rows_per_wg;
   // IC_AMD_NSPLIT forces one split for every row tile (tuning aid)
   static const int forced = [] {
     const char* v = getenv("IC_AMD_NSPLIT");
@@ -93,9 +114,9 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
     p->full_tiles = 0;
     ns = forced;
   } else {
-    p->full_tiles = p->row_tiles / num_cus * num_cus;
+    p->full_tiles = p->row_tiles / slots * slots;
     const int64_t rem = p->row_tiles - p->full_tiles;
-    ns = rem > 0 ? choose_nsplit(rem, stages, num_cus) : 1;
+    ns = rem > 0 ? choose_nsplit(rem, stages, slots) : 1;
   }
   if (ns > stages) ns = (int)stages;
   if (ns < 1) ns = 1;
@@ -113,26 +134,26 @@ __device__ __forceinline__ void glds4(const float* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-// Stage `st` = codewords [kStageK st, kStageK (st + 1)) -> LDS buffer sb.  The LDS image of a
+// Stage `st` = codewords [SK st, SK (st + 1)) -> LDS buffer sb.  The LDS image of a
 // global_load_lds is lane-linear (wave base + 16 * lane), so the padded image (528-byte rows) is
 // produced through the SOURCE address: the lane that lands on 16-byte chunk `pos` of the buffer
 // fetches chunk pos % 33 of codeword row pos / 33 (the 33rd chunk of a row is padding and re-reads
 // chunk 0).  Rows past the codebook end re-read the last row; their norm slot holds +inf, so they
 // can never win.
-template <int NW>
+template <int NW, int SK>
 __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
                                             const float* __restrict__ cnp, int st, char* sb,
                                             int wave, int lane) {
   // wave-uniform 64-bit base + 32-bit per-lane byte offset (keeps the address math off the VALU)
-  const char* base = reinterpret_cast<const char*>(C) + (size_t)st * (kStageK * kD * 4);
-  const int last = K - 1 - st * kStageK;  // last valid row of this stage (>= 0)
+  const char* base = reinterpret_cast<const char*>(C) + (size_t)st * (SK * kD * 4);
+  const int last = K - 1 - st * SK;  // last valid row of this stage (>= 0)
   // opaque copy: the offsets below are recomputed per call (a few VALU ops) instead of being
   // hoisted out of the sweep loop and held in registers the MFMA operands need
   asm volatile("" : "+v"(lane));
 #pragma unroll
-  for (int i = 0; i < (kStageGlds + NW - 1) / NW; ++i) {
+  for (int i = 0; i < (Stage<SK>::kGlds + NW - 1) / NW; ++i) {
     const int m = wave + NW * i;
-    if (m < kStageGlds) {
+    if (m < Stage<SK>::kGlds) {
       const int pos = m * 64 + lane;
       int r = (pos * 1986) >> 16;  // pos / 33, exact for pos < 4224
       int c = pos - r * kRowChunks;
@@ -143,9 +164,9 @@ __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
     }
   }
 #pragma unroll
-  for (int part = 0; part < kStageK / 64; ++part)
+  for (int part = 0; part < SK / 64; ++part)
     if (wave == NW - 1 - part)
-      glds4(cnp + (size_t)st * kStageK + part * 64 + lane, sb + kStageTileBytes + part * 256);
+      glds4(cnp + (size_t)st * SK + part * 64 + lane, sb + Stage<SK>::kTileBytes + part * 256);
 }
 
 struct Top2 {
@@ -222,13 +243,14 @@ __device__ __forceinline__ void compute_tile(const char* tile_base, const char* 
     }
   }
   // row stride 528 B: lanes i and i+1 start one 16-byte bank slot apart, so each 16-lane group of
-  // a ds_read_b128 covers all 16 slots of the 256-byte bank row (conflict free)
-  const f32x4* arow = reinterpret_cast<const f32x4*>(tile_base + i * kRowBytes + h * 256);
+  // a ds_read_b128 covers all 16 slots of the 256-byte bank row (conflict free); lane half h
+  // takes the odd (h = 1) or even 16-byte chunks of the row
+  const f32x4* arow = reinterpret_cast<const f32x4*>(tile_base + i * kRowBytes + h * 16);
   f32x4 a = arow[0];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     f32x4 an = a;
-    if (q + 1 < 16) an = arow[q + 1];
+    if (q + 1 < 16) an = arow[2 * (q + 1)];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -363,8 +385,8 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st
   }
 }
 
-template <int XT, int NW, int SKIP>
-__global__ __launch_bounds__(NW * 64) void k_top2_partial(
+template <int XT, int NW, int SK, int SKIP>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ cnp, int stages_total, int stages_per_split, int full_tiles,
     int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part) {
@@ -385,24 +407,30 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     st1 = st1 < stages_total ? st1 : stages_total;
   }
 
-  issue_stage<NW>(C, K, cnp, st0, smem, wave, lane);
-  if (st0 + 1 < st1) issue_stage<NW>(C, K, cnp, st0 + 1, smem + kStageBytes, wave, lane);
-
-  // descriptors of this wave, scaled by -2 (exact), 64 components per lane
+  // descriptors of this wave, scaled by -2 (exact), 64 components per lane.  Their loads go out
+  // first, then the first two stages of the codebook.
   const int64_t row0 = (int64_t)rt * (XT * NW * 32) + (int64_t)wave * (XT * 32);
-  float xr[XT][64];
+  f32x4 xv[XT][16];
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
     int64_t r = row0 + xt * 32 + j;
     r = r < N ? r : N - 1;
-    const f32x4* p = reinterpret_cast<const f32x4*>(X + r * kD + h * 64);
+    const f32x4* p = reinterpret_cast<const f32x4*>(X + r * kD + h * 4);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xv[xt][q] = p[2 * q];
+  }
+  issue_stage<NW, SK>(C, K, cnp, st0, smem, wave, lane);
+  const bool two = st0 + 1 < st1;
+  if (two) issue_stage<NW, SK>(C, K, cnp, st0 + 1, smem + Stage<SK>::kBytes, wave, lane);
+  float xr[XT][64];
+#pragma unroll
+  for (int xt = 0; xt < XT; ++xt) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const f32x4 v = p[q];
-      xr[xt][q * 4 + 0] = -2.0f * v[0];
-      xr[xt][q * 4 + 1] = -2.0f * v[1];
-      xr[xt][q * 4 + 2] = -2.0f * v[2];
-      xr[xt][q * 4 + 3] = -2.0f * v[3];
+      xr[xt][q * 4 + 0] = -2.0f * xv[xt][q][0];
+      xr[xt][q * 4 + 1] = -2.0f * xv[xt][q][1];
+      xr[xt][q * 4 + 2] = -2.0f * xv[xt][q][2];
+      xr[xt][q * 4 + 3] = -2.0f * xv[xt][q][3];
     }
   }
 
@@ -423,29 +451,33 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     gate[xt] = start;
   }
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // loads return in order: with the second stage in flight (at least 8 loads per wave, issued
+  // last) the rows and the first stage are complete once at most 8 loads are outstanding
+  static_assert(Stage<SK>::kGlds / NW >= 8, "the wait below assumes 8 loads per wave and stage");
+  if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   f32x16 acc[XT];
   for (int st = st0; st < st1; ++st) {
-    char* sb = smem + ((st - st0) & 1) * kStageBytes;
+    char* sb = smem + ((st - st0) & 1) * Stage<SK>::kBytes;
 #pragma unroll
-    for (int t = 0; t < kTilesPerStage; ++t) {
+    for (int t = 0; t < Stage<SK>::kTiles; ++t) {
       // tiles that lie wholly past the end of the codebook (padding of the last stage) are skipped
-      const bool live = (st * kTilesPerStage + t) * kTileK < K;
+      const bool live = (st * Stage<SK>::kTiles + t) * kTileK < K;
       if (live)
-        compute_tile<XT>(sb + t * kTileK * kRowBytes, sb + kStageTileBytes + t * kTileK * 4, xr,
+        compute_tile<XT>(sb + t * kTileK * kRowBytes, sb + Stage<SK>::kTileBytes + t * kTileK * 4, xr,
                          acc, j, h);
-      if (t == kTilesPerStage - 1) {
+      if (t == Stage<SK>::kTiles - 1) {
         // every wave is done reading this buffer once it passes the barrier; the stage issued one
         // iteration ago has landed in the other buffer by then
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (st + 2 < st1) issue_stage<NW>(C, K, cnp, st + 2, sb, wave, lane);
+        if (st + 2 < st1) issue_stage<NW, SK>(C, K, cnp, st + 2, sb, wave, lane);
         if constexpr (SKIP == 3) sync_gate<XT>(best, gate);
       }
       if (live) {
-        const int encbase = (st * kTilesPerStage + t) * 16;
+        const int encbase = (st * Stage<SK>::kTiles + t) * 16;
         if constexpr (SKIP == 3) tile_epilogue_skip3<XT>(acc, best, gate, encbase);
         else if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, encbase);
         else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, encbase);
@@ -479,10 +511,11 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   }
 }
 
-hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, const AssignPlan& plan, const float* thr,
-                               ic_top2_rec* part, hipStream_t s) {
-  const int64_t stages = (k + kStageK - 1) / kStageK;
+template <int NW, int SK>
+static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
+                                  const float* cn_pad, const AssignPlan& plan, const float* thr,
+                                  ic_top2_rec* part, hipStream_t s) {
+  const int64_t stages = (k + SK - 1) / SK;
   const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
   // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
   // candidate, 1 = skip tiles no lane can improve, 2 = also skip registers, 3 (default) = the
@@ -491,20 +524,30 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
     const char* v = getenv("IC_AMD_VARIANT");
     return v ? atoi(v) : 3;
   }();
-  auto kern = variant == 0 ? k_top2_partial<kXT, kNW, 0>
-              : variant == 1 ? k_top2_partial<kXT, kNW, 1>
-              : variant == 3 ? k_top2_partial<kXT, kNW, 3> : k_top2_partial<kXT, kNW, 2>;
-  const int lds = 2 * kStageBytes;
+  auto kern = variant == 0 ? k_top2_partial<kXT, NW, SK, 0>
+              : variant == 1 ? k_top2_partial<kXT, NW, SK, 1>
+              : variant == 3 ? k_top2_partial<kXT, NW, SK, 3> : k_top2_partial<kXT, NW, SK, 2>;
+  const int lds = 2 * Stage<SK>::kBytes;
   // per device and cheap, so it is simply repeated on every call
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   const int64_t grid = plan.full_tiles + split_tiles * plan.nsplit;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kNW * 64), lds, s, x, n, c, (int)k, cn_pad,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, cn_pad,
                      (int)stages, plan.stages_per_split, (int)plan.full_tiles, (int)split_tiles,
                      thr, part);
   return hipGetLastError();
+}
+
+hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
+                               const float* cn_pad, const AssignPlan& plan, const float* thr,
+                               ic_top2_rec* part, hipStream_t s) {
+  if (plan.waves == 4 && plan.stage_k == 64)
+    return launch_geometry<4, 64>(x, n, c, k, cn_pad, plan, thr, part, s);
+  if (plan.waves == 8 && plan.stage_k == 128)
+    return launch_geometry<8, 128>(x, n, c, k, cn_pad, plan, thr, part, s);
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,7 +629,7 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_to
   if (grid > 16384) grid = 16384;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, part, plan.nsplit,
-                     plan.full_tiles * (int64_t)kRowsPerWg, i1, d1, i2, d2, ratio, mask, rec);
+                     plan.full_tiles * (int64_t)plan.rows_per_wg, i1, d1, i2, d2, ratio, mask, rec);
   return hipGetLastError();
 }
 

@@ -10,18 +10,18 @@
 namespace ic {
 
 constexpr int kD = 128;      // padded descriptor dimension the MFMA kernel contracts over
-constexpr int kStageK = 128;  // codewords staged in LDS per pipeline stage (4 MFMA tiles of 32)
+constexpr int kStageK = 128;  // codebook norms are padded to a multiple of this (the largest stage)
 constexpr int kMaxShards = 64;  // shard bases of ic_top2_merge travel as a kernel argument
 
 static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 
 // ---- ic_assign.hip ---------------------------------------------------------------------------
-// Rows per workgroup of the distance kernel (x-tile rows kept in registers by one workgroup).
-int assign_rows_per_wg();
-// Decomposition of one search: the first full_tiles row tiles are scanned over the whole
-// codebook by one workgroup each, the remaining ones in nsplit K-splits of stages_per_split
-// stages; the partial buffer holds nsplit * n records.
+// Decomposition of one search.  Geometry: workgroups of `waves` waves hold rows_per_wg rows in
+// registers and stream the codebook through LDS in stages of stage_k codewords.  The first
+// full_tiles row tiles are scanned over the whole codebook by one workgroup each, the remaining
+// ones in nsplit K-splits of stages_per_split stages; the partial buffer holds nsplit * n records.
 struct AssignPlan {
+  int waves, stage_k, rows_per_wg;
   int64_t row_tiles, full_tiles;
   int nsplit, stages_per_split;
 };
