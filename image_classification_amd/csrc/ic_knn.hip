@@ -5,7 +5,8 @@
 // matrix product, so the kernels are plain VALU work staged through LDS:
 //
 //   k_pairdist<METRIC>  64 x 64 tile of the distance matrix per workgroup, 4 x 4 per lane,
-//                       32 components per LDS stage, f32 inside a stage, f64 across stages
+//                       64 components per LDS stage (the next one prefetched into registers),
+//                       f32 inside a stage, f64 across stages
 //   k_topk_rows         one workgroup per search row: k rounds of "smallest (distance, index)
 //                       pair above the previous one", so ties resolve to the lowest index
 #include "ic_internal.h"
@@ -15,7 +16,7 @@ namespace ic {
 namespace {
 
 constexpr int kTile = 64;      // rows of either operand per workgroup tile
-constexpr int kChunk = 32;     // components per LDS stage
+constexpr int kChunk = 64;     // components per LDS stage
 constexpr int kLdsStride = 68; // floats per staged component (64 rows + pad, keeps 16-byte alignment)
 constexpr int kPairThreads = 256;
 constexpr int kTopkThreads = 256;
@@ -33,27 +34,77 @@ __device__ __forceinline__ float pair_term(float a, float b) {
   return t * t;
 }
 
-// stage rows [r0, r0+64) x components [d0, d0+32) of `src` into lds[comp][row]; zero outside
-__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int64_t rows, int d,
-                                           int64_t r0, int d0, float* lds) {
+// One staged chunk of one operand as it travels through registers: rows [r0, r0+64) x components
+// [d0, d0+kChunk), 16 floats per thread.  Lane -> row, so the transposed store lds[comp][row] is
+// conflict free; the loads of a wave touch 64 rows but every cache line they open is used up by
+// the wave's following loads.
+struct Staged {
+  float4 v[kChunk / 16];
+};
+
+template <bool VEC>
+__device__ __forceinline__ void load_chunk(const float* __restrict__ src, int64_t rows, int d,
+                                           int64_t r0, int d0, Staged& st) {
+  const int row = threadIdx.x % kTile;
+  const int q0 = threadIdx.x / kTile;          // 0..3: which float4 of every group of four
+  const int64_t gr = r0 + row;
+  const float* p = src + (gr < rows ? gr : 0) * (int64_t)d;
 #pragma unroll
-  for (int e = 0; e < kTile * kChunk / kPairThreads; ++e) {
-    const int idx = threadIdx.x + e * kPairThreads;
-    const int row = idx / kChunk, col = idx % kChunk;
-    const int64_t gr = r0 + row;
-    const int gc = d0 + col;
-    const bool ok = gr < rows && gc < d;
-    const float v = src[ok ? gr * d + gc : 0];
-    lds[col * kLdsStride + row] = ok ? v : 0.f;
+  for (int e = 0; e < kChunk / 16; ++e) {
+    const int gc = d0 + (e * 4 + q0) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC) {
+      if (gr < rows && gc < d) v = *reinterpret_cast<const float4*>(p + gc);   // d % 4 == 0
+    } else if (gr < rows) {
+      if (gc + 0 < d) v.x = p[gc + 0];
+      if (gc + 1 < d) v.y = p[gc + 1];
+      if (gc + 2 < d) v.z = p[gc + 2];
+      if (gc + 3 < d) v.w = p[gc + 3];
+    }
+    st.v[e] = v;
   }
 }
 
-template <int METRIC>
+__device__ __forceinline__ void store_chunk(const Staged& st, float* lds) {
+  const int row = threadIdx.x % kTile;
+  const int q0 = threadIdx.x / kTile;
+#pragma unroll
+  for (int e = 0; e < kChunk / 16; ++e) {
+    const int col = (e * 4 + q0) * 4;
+    lds[(col + 0) * kLdsStride + row] = st.v[e].x;
+    lds[(col + 1) * kLdsStride + row] = st.v[e].y;
+    lds[(col + 2) * kLdsStride + row] = st.v[e].z;
+    lds[(col + 3) * kLdsStride + row] = st.v[e].w;
+  }
+}
+
+// chi-square divides by the first operand: its reciprocal is taken once per staged element, not
+// once per pair (0 where OpenCV's CV_COMP_CHISQR skips the bin)
+__device__ __forceinline__ float chisqr_weight(float a) {
+  return fabsf(a) > 2.2204460492503131e-16f ? 1.0f / a : 0.f;
+}
+
+__device__ __forceinline__ void store_chunk_weights(const Staged& st, float* lds) {
+  const int row = threadIdx.x % kTile;
+  const int q0 = threadIdx.x / kTile;
+#pragma unroll
+  for (int e = 0; e < kChunk / 16; ++e) {
+    const int col = (e * 4 + q0) * 4;
+    lds[(col + 0) * kLdsStride + row] = chisqr_weight(st.v[e].x);
+    lds[(col + 1) * kLdsStride + row] = chisqr_weight(st.v[e].y);
+    lds[(col + 2) * kLdsStride + row] = chisqr_weight(st.v[e].z);
+    lds[(col + 3) * kLdsStride + row] = chisqr_weight(st.v[e].w);
+  }
+}
+
+template <int METRIC, bool VEC>
 __global__ __launch_bounds__(kPairThreads) void k_pairdist(
     const float* __restrict__ x, int64_t m, const float* __restrict__ c, int64_t n, int d,
     double* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float xs[kChunk * kLdsStride];
   __shared__ __attribute__((aligned(16))) float cs[kChunk * kLdsStride];
+  constexpr bool kChi = METRIC == IC_METRIC_CHISQR;
+  __shared__ __attribute__((aligned(16))) float ws[kChi ? kChunk * kLdsStride : 4];
   const int64_t c0 = (int64_t)blockIdx.x * kTile;
   const int64_t x0 = (int64_t)blockIdx.y * kTile;
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
@@ -64,11 +115,20 @@ __global__ __launch_bounds__(kPairThreads) void k_pairdist(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
 
+  // the next chunk is fetched into registers while the current one is being compared
+  Staged sx, sc;
+  load_chunk<VEC>(x, m, d, x0, 0, sx);
+  load_chunk<VEC>(c, n, d, c0, 0, sc);
   for (int d0 = 0; d0 < d; d0 += kChunk) {
     __syncthreads();
-    stage_tile(x, m, d, x0, d0, xs);
-    stage_tile(c, n, d, c0, d0, cs);
+    store_chunk(sx, xs);
+    store_chunk(sc, cs);
+    if (kChi) store_chunk_weights(sx, ws);
     __syncthreads();
+    if (d0 + kChunk < d) {
+      load_chunk<VEC>(x, m, d, x0, d0 + kChunk, sx);
+      load_chunk<VEC>(c, n, d, c0, d0 + kChunk, sc);
+    }
     float part[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -80,10 +140,22 @@ __global__ __launch_bounds__(kPairThreads) void k_pairdist(
       const float4 b = *reinterpret_cast<const float4*>(&cs[kk * kLdsStride + tx * 4]);
       const float av[4] = {a.x, a.y, a.z, a.w};
       const float bv[4] = {b.x, b.y, b.z, b.w};
+      if (kChi) {
+        const float4 w = *reinterpret_cast<const float4*>(&ws[kk * kLdsStride + ty * 4]);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[i][j] += pair_term<METRIC>(av[i], bv[j]);
+          for (int j = 0; j < 4; ++j) {
+            const float t = av[i] - bv[j];
+            part[i][j] = __builtin_fmaf(t * t, wv[i], part[i][j]);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) part[i][j] += pair_term<METRIC>(av[i], bv[j]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -313,6 +385,18 @@ static void launch_few(const float* x, int64_t m, const float* c, int64_t n, int
   }
 }
 
+template <int METRIC>
+void launch_tiled(const float* x, int64_t m, const float* c, int64_t n, int d, double* out,
+                  hipStream_t s) {
+  const dim3 grid((unsigned)((n + kTile - 1) / kTile), (unsigned)((m + kTile - 1) / kTile));
+  const dim3 block(kPairThreads);
+  // 16-byte loads need rows that start on 16-byte boundaries
+  const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(c) & 15) == 0;
+  if (vec) hipLaunchKernelGGL((k_pairdist<METRIC, true>), grid, block, 0, s, x, m, c, n, d, out);
+  else hipLaunchKernelGGL((k_pairdist<METRIC, false>), grid, block, 0, s, x, m, c, n, d, out);
+}
+
 hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n, int d, int metric,
                            double* out, hipStream_t s) {
   if (m <= kFewMax) {
@@ -326,26 +410,13 @@ hipError_t launch_pairdist(const float* x, int64_t m, const float* c, int64_t n,
     }
     return hipGetLastError();
   }
-  const dim3 grid((unsigned)((n + kTile - 1) / kTile), (unsigned)((m + kTile - 1) / kTile));
-  const dim3 block(kPairThreads);
   switch (metric) {
-    case IC_METRIC_EUCLIDEAN:
-      hipLaunchKernelGGL(k_pairdist<IC_METRIC_EUCLIDEAN>, grid, block, 0, s, x, m, c, n, d, out);
-      break;
-    case IC_METRIC_SQEUCLIDEAN:
-      hipLaunchKernelGGL(k_pairdist<IC_METRIC_SQEUCLIDEAN>, grid, block, 0, s, x, m, c, n, d, out);
-      break;
-    case IC_METRIC_L1:
-      hipLaunchKernelGGL(k_pairdist<IC_METRIC_L1>, grid, block, 0, s, x, m, c, n, d, out);
-      break;
-    case IC_METRIC_INTERSECTION:
-      hipLaunchKernelGGL(k_pairdist<IC_METRIC_INTERSECTION>, grid, block, 0, s, x, m, c, n, d, out);
-      break;
-    case IC_METRIC_CHISQR:
-      hipLaunchKernelGGL(k_pairdist<IC_METRIC_CHISQR>, grid, block, 0, s, x, m, c, n, d, out);
-      break;
-    default:
-      return hipErrorInvalidValue;
+    case IC_METRIC_EUCLIDEAN: launch_tiled<IC_METRIC_EUCLIDEAN>(x, m, c, n, d, out, s); break;
+    case IC_METRIC_SQEUCLIDEAN: launch_tiled<IC_METRIC_SQEUCLIDEAN>(x, m, c, n, d, out, s); break;
+    case IC_METRIC_L1: launch_tiled<IC_METRIC_L1>(x, m, c, n, d, out, s); break;
+    case IC_METRIC_INTERSECTION: launch_tiled<IC_METRIC_INTERSECTION>(x, m, c, n, d, out, s); break;
+    case IC_METRIC_CHISQR: launch_tiled<IC_METRIC_CHISQR>(x, m, c, n, d, out, s); break;
+    default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
