@@ -305,7 +305,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = ops.profile_end(local_rank)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())

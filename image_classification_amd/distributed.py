@@ -77,9 +77,28 @@ def quantize_sharded(x_local, offsets_local, codebook, norm="l1", power=0.5, bac
 
 
 def _staged(t, group):
-    """gloo moves device tensors for all_reduce / broadcast only; the gathers go through host
-    copies when several ranks rehearse the multi-GPU path over gloo (RCCL gathers in place)."""
+    """Over gloo (several ranks rehearsing the multi-GPU path on one device, or CPU tests) device
+    tensors travel through host copies; RCCL works on them in place."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, group, op=None):
+    op = op if op is not None else dist.ReduceOp.SUM
+    if _staged(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _broadcast(t, src, group):
+    if _staged(t, group):
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=group)
 
 
 def _all_gather_into(flat, t, group):
@@ -98,7 +117,7 @@ def gather_rows(t, group=None):
         return [t]
     sizes = torch.zeros(n, dtype=torch.int64, device=t.device)
     sizes[rank] = t.shape[0]
-    dist.all_reduce(sizes, group=group)
+    _all_reduce(sizes, group)
     sizes = [int(s) for s in sizes.cpu()]
     m = max(sizes)
     padded = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -115,7 +134,7 @@ def make_allreduce(group=None):
         buf = torch.empty(k * d + k, dtype=torch.float64, device=sums.device)
         buf[:k * d] = sums.reshape(-1)
         buf[k * d:] = counts.to(torch.float64)      # exact below 2^53 members
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(buf, group)
         sums.copy_(buf[:k * d].reshape(k, d))
         counts.copy_(buf[k * d:].round().to(torch.int64))
     return allreduce
@@ -133,8 +152,7 @@ def kmeans_fit_sharded(x_local, init, iters, backend=None, group=None, on_empty=
     xd = b.f32(x_local)
     c0 = b.f32(init)
     if n > 1:
-        dist.broadcast(c0, src=dist.get_global_rank(group, 0) if group is not None else 0,
-                       group=group)
+        _broadcast(c0, dist.get_global_rank(group, 0) if group is not None else 0, group)
     return lloyd(xd, c0, iters, b, allreduce=make_allreduce(group) if n > 1 else None,
                  on_empty=on_empty)
 
@@ -156,7 +174,7 @@ def knn2_index_sharded(queries, index_local, index_base, ratio=0.8, backend=None
     gathered = flat.view(n, rows, rec.shape[1])
     bases = torch.zeros(n, dtype=torch.int64, device=rec.device)
     bases[rank] = int(index_base)
-    dist.all_reduce(bases, group=group)
+    _all_reduce(bases, group)
     return b.top2_merge(gathered, [int(v) for v in bases.cpu()], ratio)
 
 
