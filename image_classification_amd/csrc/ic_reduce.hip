@@ -10,14 +10,18 @@
 namespace ic {
 
 // ---------------------------------------------------------------------------------------------
-// Histogram.  One workgroup per (image, bin range).  The image's codes are taken in chunks of up
-// to 4096: a chunk is sorted in LDS (bitonic network), so equal codes form runs; the thread on a
-// run's first element subtracts its position from that code's bin, and after a barrier the thread
-// on the run's last element adds position + 1.  A bin is touched by one thread per pass.
+// Histogram.  One workgroup of four waves per (image, bin range).  Wave w counts the codes whose
+// two low bits are w, so the waves write disjoint bins and need no barrier between them.  A wave
+// takes 64 codes at a time; lanes holding the same code must not add to its bin in the same
+// instruction, so the lanes first elect one owner per code: every pending lane writes its lane
+// number into a tag slot chosen by the code, reads the slot back, and the lane that finds its own
+// number adds 1 to the bin and retires.  Lanes that lost (same code, or another code on the same
+// slot) go round again.  LDS operations of one wave execute in order, owners of one round hold
+// different codes, and so every bin has exactly one writer per instruction: no atomics, and the
+// counts do not depend on which lane wins.
 constexpr int kHistThreads = 256;
-constexpr int kSortChunk = 4096;
-constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB + 16 KiB sort buffer of LDS
-constexpr unsigned kNoCode = 0xFFFFFFFFu;
+constexpr int kTagSlots = 1024;      // tag slots per wave
+constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB + 16 KiB of tags in LDS
 
 __device__ __forceinline__ double block_sum(double v, double* red /*[kHistThreads/64]*/) {
 #pragma unroll
@@ -61,49 +65,43 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
   int64_t nb64 = k - bin0;
   if (nb64 > bins_per_wg) nb64 = bins_per_wg;
   const unsigned nb = (unsigned)nb64;
-  unsigned* hist = hsm;
-  unsigned* buf = hsm + bins_per_wg;
+  volatile unsigned* hist = hsm;
+  const int wave = tid >> 6, lane = tid & 63;
+  volatile unsigned* tags = hsm + bins_per_wg + wave * kTagSlots;
 
   for (unsigned b = tid; b < nb; b += kHistThreads) hist[b] = 0;
   const int64_t beg = offsets[img], end = offsets[img + 1];
+  __syncthreads();
 
-  for (int64_t base = beg; base < end; base += kSortChunk) {
-    const int64_t left = end - base;
-    const int cnt = left < kSortChunk ? (int)left : kSortChunk;
-    int P = 2 * kHistThreads;
-    while (P < cnt) P <<= 1;
-    __syncthreads();
-    for (int p = tid; p < P; p += kHistThreads) {
-      unsigned v = kNoCode;
-      if (p < cnt) {
-        const int64_t c = (int64_t)codes[base + p] - bin0;
-        if (c >= 0 && c < (int64_t)nb) v = (unsigned)c;
-      }
-      buf[p] = v;
+  // four 64-code pieces per step; the next step's codes are fetched before this step's are counted
+  constexpr int kU = 4;
+  int32_t nxt[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t i = beg + u * 64 + lane;
+    nxt[u] = i < end ? codes[i] : -1;
+  }
+  for (int64_t base = beg; base < end; base += kU * 64) {
+    int32_t cur[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      cur[u] = nxt[u];
+      const int64_t i = base + (kU + u) * 64 + lane;
+      nxt[u] = i < end ? codes[i] : -1;
     }
-    for (int size = 2; size <= P; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        __syncthreads();
-        for (int t = tid; t < P / 2; t += kHistThreads) {
-          const int pos = 2 * t - (t & (stride - 1));
-          const unsigned a = buf[pos], b = buf[pos + stride];
-          const bool up = (pos & size) == 0;
-          if ((a > b) == up) {
-            buf[pos] = b;
-            buf[pos + stride] = a;
-          }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t c = (int64_t)cur[u] - bin0;
+      bool pending = cur[u] >= 0 && c >= 0 && c < (int64_t)nb && (int)(c & 3) == wave;
+      const unsigned code = (unsigned)c;
+      const unsigned slot = (code >> 2) & (kTagSlots - 1);
+      while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+        if (pending) tags[slot] = (unsigned)lane;
+        if (pending && tags[slot] == (unsigned)lane) {
+          hist[code] = hist[code] + 1u;
+          pending = false;
         }
       }
-    }
-    __syncthreads();
-    for (int p = tid; p < P; p += kHistThreads) {
-      const unsigned v = buf[p];
-      if (v != kNoCode && (p == 0 || buf[p - 1] != v)) hist[v] -= (unsigned)p;
-    }
-    __syncthreads();
-    for (int p = tid; p < P; p += kHistThreads) {
-      const unsigned v = buf[p];
-      if (v != kNoCode && (p == P - 1 || buf[p + 1] != v)) hist[v] += (unsigned)(p + 1);
     }
   }
   __syncthreads();
@@ -163,7 +161,7 @@ hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_i
   const int bins_per_wg = k < kHistMaxBins ? (int)k : kHistMaxBins;
   const int64_t n_ranges = (k + bins_per_wg - 1) / bins_per_wg;
   if (n_img > 0x7fffffffLL || n_ranges > 65535) return hipErrorInvalidValue;
-  const int lds = (bins_per_wg + kSortChunk) * 4;
+  const int lds = (bins_per_wg + (kHistThreads / 64) * kTagSlots) * 4;
   // per device and cheap, so it is simply repeated on every call
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
