@@ -16,7 +16,9 @@ namespace ic {
 // instruction, so the lanes first elect one owner per code: every pending lane writes its lane
 // number into a tag slot chosen by the code, reads the slot back, and the lane that finds its own
 // number adds 1 to the bin and retires.  Lanes that lost (same code, or another code on the same
-// slot) go round again.  LDS operations of one wave execute in order, owners of one round hold
+// slot) go round again; after two rounds the rest is retired one distinct code at a time (ballot
+// of the lanes that hold the first pending lane's code), which bounds the work for images whose
+// descriptors all map to a few words.  LDS operations of one wave execute in order, owners of one round hold
 // different codes, and so every bin has exactly one writer per instruction: no atomics, and the
 // counts do not depend on which lane wins.
 constexpr int kHistThreads = 256;
@@ -95,11 +97,24 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
       bool pending = cur[u] >= 0 && c >= 0 && c < (int64_t)nb && (int)(c & 3) == wave;
       const unsigned code = (unsigned)c;
       const unsigned slot = (code >> 2) & (kTagSlots - 1);
-      while (__builtin_amdgcn_ballot_w64(pending) != 0) {
-        if (pending) tags[slot] = (unsigned)lane;
-        if (pending && tags[slot] == (unsigned)lane) {
-          hist[code] = hist[code] + 1u;
-          pending = false;
+      int rounds = 0;
+      unsigned long long left;
+      while ((left = __builtin_amdgcn_ballot_w64(pending)) != 0) {
+        if (rounds < 2) {
+          ++rounds;
+          if (pending) tags[slot] = (unsigned)lane;
+          if (pending && tags[slot] == (unsigned)lane) {
+            hist[code] = hist[code] + 1u;
+            pending = false;
+          }
+        } else {
+          // many lanes hold the same code (a blank frame maps every descriptor to one word):
+          // retire all lanes of the first pending lane's code at once
+          const int first = __builtin_amdgcn_readfirstlane(__builtin_ctzll(left));
+          const unsigned c0 = (unsigned)__builtin_amdgcn_readlane((int)code, first);
+          const unsigned long long same = __builtin_amdgcn_ballot_w64(pending && code == c0);
+          if (lane == first) hist[c0] = hist[c0] + (unsigned)__builtin_popcountll(same);
+          pending = pending && code != c0;
         }
       }
     }
