@@ -61,6 +61,21 @@ def test_hist_image_larger_than_one_sort_chunk_and_skewed_codes():
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("words", [1, 8, 70])
+def test_hist_images_whose_codes_fall_on_a_few_words(words):
+    # blank frames: every descriptor of an image maps to the same handful of words, all with the
+    # same two low bits, so one wave counts them and most lanes of a piece hold equal codes
+    rng = np.random.default_rng(words)
+    k = 10000
+    offsets = image_offsets(9, 2000, ragged=True, seed=5)
+    vocab_subset = (rng.choice(k // 4, size=words, replace=False) * 4 + 2).astype(np.int32)
+    codes = vocab_subset[rng.integers(0, words, size=offsets[-1])]
+    for norm in ("none", "l1"):
+        got = _hist(codes, offsets, k, norm)
+        ref = oracle.build_histogram(_split(codes, offsets), k, norm)
+        assert np.array_equal(got, ref)
+
+
 def test_hist_ignores_codes_outside_the_vocabulary():
     codes = np.array([0, 5, -1, 7, 99, 5, 2 ** 31 - 1], dtype=np.int32)
     got = _hist(codes, [0, 7], 8, "l1")
