@@ -18,6 +18,8 @@ def test_search_hist_centroid_over_random_shapes():
     for trial in range(40):
         n = int(rng.integers(1, 3000))
         k = int(rng.integers(1, 700))
+        if trial % 5 == 4:
+            k = int(rng.integers(2048, 4200))     # the workgroup geometry of large codebooks
         d = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 100, 127, 128]))
         scale = float(rng.choice([0.01, 1.0, 300.0]))
         x = (rng.standard_normal((n, d)) * scale).astype(np.float32)
@@ -66,3 +68,16 @@ def test_knn_rows_over_random_shapes():
         tag = "trial %d: m=%d n=%d d=%d k=%d %s" % (trial, m, n, d, k, metric)
         assert same.mean() > 0.99, tag
         assert oracle.check_close(dist.cpu().numpy()[same], rd[same], abs_floor=1e-9) <= 1e-4, tag
+
+
+def test_search_against_direct_search_over_random_shapes(monkeypatch):
+    # tools/soak.py: both workgroup geometries, K-splits, padded widths, ties, hints, shard merge,
+    # each case checked on the device against the search by direct differences
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py")
+    spec = importlib.util.spec_from_file_location("ic_soak", path)
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    monkeypatch.setattr("sys.argv", ["soak.py", "150", "11"])
+    soak.main()
