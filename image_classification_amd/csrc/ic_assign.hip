@@ -15,7 +15,7 @@
 //     (h = 0) or odd (h = 1) 16-byte chunks of "its" row, for both operands.  The two lanes of a
 //     descriptor then fetch neighbouring chunks, so a load instruction touches 32 cache lines,
 //     not 64.
-//   * a wave keeps XT tiles of 32 descriptors (pre-scaled by -2) in registers for the whole sweep
+//   * a wave keeps one tile of 32 descriptors (pre-scaled by -2) in registers for the whole sweep
 //     over the codebook; the accumulator is initialised with |c|^2, so the MFMA chain leaves
 //     |c|^2 - 2 x.c directly (|x|^2 is constant per row and cannot change the argmin).
 //   * codeword tiles are staged global -> LDS with global_load_lds (16 B per lane), two stage
@@ -53,19 +53,20 @@ struct Stage {
   static_assert(kStageK % SK == 0, "the padded norms must cover whole stages");
 };
 
-// Two geometries, both with two waves per SIMD (LDS-read latency, barriers and the 18 wait states
-// between an MFMA and a vector read of its result are covered by the partner wave), each wave
-// holding 2 x 32 descriptors; 190 VGPRs, no spills.  (Four waves holding 4 x 32 descriptors each,
-// one wave per SIMD, made hipcc spill 170+ registers and was dropped.)
-//   large: one workgroup of 8 waves per CU, stages of 128 codewords (136 KB of LDS);
-//   small: two workgroups of 4 waves per CU, stages of 64 codewords (68 KB each).  A workgroup
-//          spends about 10 us loading its rows and first stages before it multiplies; with two
-//          independent workgroups on a CU one of them multiplies meanwhile.  That pays while the
-//          scan is short (measured: 64 -> 70 % of peak at 256 codewords, 77.6 -> 80 % at 1000,
-//          equal at 2000, -0.7 points at 10 000 where the extra barriers and codebook reads cost
-//          more than the hidden prologue).
-constexpr int kXT = 2;
-constexpr int kSmallCodebook = 2048;   // below this the small geometry is used
+// Geometry.  Every wave holds ONE tile of 32 descriptors (64 components per lane, 102 VGPRs), so
+// four waves fit a SIMD: while one wave ranks, waits for the last MFMA of its tile, for an LDS
+// read or at the stage barrier, three others have MFMAs to issue.  (Two tiles per wave and two
+// waves per SIMD, the first layout, left the matrix pipe idle about 6 % of the time; four tiles
+// per wave made hipcc spill.)  Two shapes of workgroup:
+//   large codebooks: one workgroup of 16 waves per CU, stages of 128 codewords (136 KB of LDS);
+//   others:          two workgroups of 8 waves per CU, stages of 64 codewords (68 KB each).  A
+//                    workgroup spends about 10 us loading its rows and first stages before it
+//                    multiplies; with two independent workgroups on a CU the other one multiplies
+//                    meanwhile, which matters while the scan is short.
+// Measured (% of the fp32 MFMA peak, two workgroups / one workgroup): 256 codewords 74.1 / 65.1,
+// 1000: 83.8 / 80.2, 4000: 89.0 / 88.0, 6000: 88.4 / 88.5, 10 000: 89.3 / 89.5, 20 000: 90.3 / 90.7.
+constexpr int kXT = 1;
+constexpr int kSmallCodebook = 8192;   // below this: two 8-wave workgroups per CU
 
 // K-split that finishes `row_tiles` row tiles soonest on `num_cus` workgroup slots.
 static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
@@ -92,16 +93,16 @@ static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
 // its top-2, so ranking gets cheaper, and X is read once); only the row tiles of the last, partly
 // filled round are split along K so that their pieces spread over all CUs.
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
-  // IC_AMD_GEOMETRY forces a geometry (1 = small, 2 = large; tuning aid)
+  // IC_AMD_GEOMETRY forces a shape (1 = two 8-wave workgroups per CU, 2 = one of 16; tuning aid)
   static const int geom = [] {
     const char* v = getenv("IC_AMD_GEOMETRY");
     return v ? atoi(v) : 0;
   }();
   const bool small = geom == 1 || (geom != 2 && k < kSmallCodebook);
-  p->waves = small ? 4 : 8;
+  p->waves = small ? 8 : 16;
   p->stage_k = small ? 64 : 128;
   p->rows_per_wg = kXT * p->waves * 32;
-  const int slots = num_cus * (8 / p->waves);  // workgroups resident at once
+  const int slots = num_cus * (small ? 2 : 1);  // workgroups resident at once
   const int64_t stages = (k + p->stage_k - 1) / p->stage_k;
   p->row_tiles = (n + p->rows_per_wg - 1) / p->rows_per_wg;
   // IC_AMD_NSPLIT forces one split for every row tile (tuning aid)
@@ -386,7 +387,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st
 }
 
 template <int XT, int NW, int SK, int SKIP>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_top2_partial(
+__global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ cnp, int stages_total, int stages_per_split, int full_tiles,
     int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part) {
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   // loads return in order: with the second stage in flight (at least 8 loads per wave, issued
   // last) the rows and the first stage are complete once at most 8 loads are outstanding
-  static_assert(Stage<SK>::kGlds / NW >= 8, "the wait below assumes 8 loads per wave and stage");
-  if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  constexpr int kMinLoads = Stage<SK>::kGlds / NW;
+  if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMinLoads) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -518,11 +519,13 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   const int64_t stages = (k + SK - 1) / SK;
   const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
   // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
-  // candidate, 1 = skip tiles no lane can improve, 2 = also skip registers, 3 (default) = the
-  // same against the bound the two lanes of a descriptor share
+  // candidate, 1 = skip tiles no lane can improve, 2 (default) = also skip registers, 3 = the
+  // same against the bound the two lanes of a descriptor share (fewer ranked candidates, but with
+  // four waves per SIMD the exchange costs what it saves: 89.9 vs 89.8 % at 10 000 codewords,
+  // 84.3 vs 85.3 % at 1000)
   static const int variant = [] {
     const char* v = getenv("IC_AMD_VARIANT");
-    return v ? atoi(v) : 3;
+    return v ? atoi(v) : 2;
   }();
   auto kern = variant == 0 ? k_top2_partial<kXT, NW, SK, 0>
               : variant == 1 ? k_top2_partial<kXT, NW, SK, 1>
@@ -543,10 +546,10 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* cn_pad, const AssignPlan& plan, const float* thr,
                                ic_top2_rec* part, hipStream_t s) {
-  if (plan.waves == 4 && plan.stage_k == 64)
-    return launch_geometry<4, 64>(x, n, c, k, cn_pad, plan, thr, part, s);
-  if (plan.waves == 8 && plan.stage_k == 128)
-    return launch_geometry<8, 128>(x, n, c, k, cn_pad, plan, thr, part, s);
+  if (plan.waves == 8 && plan.stage_k == 64)
+    return launch_geometry<8, 64>(x, n, c, k, cn_pad, plan, thr, part, s);
+  if (plan.waves == 16 && plan.stage_k == 128)
+    return launch_geometry<16, 128>(x, n, c, k, cn_pad, plan, thr, part, s);
   return hipErrorInvalidValue;
 }
 
