@@ -53,7 +53,7 @@ struct Stage {
   static_assert(kStageK % SK == 0, "the padded norms must cover whole stages");
 };
 
-// Geometry.  Every wave holds ONE tile of 32 descriptors (64 components per lane, 102 VGPRs), so
+// Geometry.  Every wave holds ONE tile of 32 descriptors (64 components per lane, 96 VGPRs), so
 // four waves fit a SIMD: while one wave ranks, waits for the last MFMA of its tile, for an LDS
 // read or at the stage barrier, three others have MFMAs to issue.  (Two tiles per wave and two
 // waves per SIMD, the first layout, left the matrix pipe idle about 6 % of the time; four tiles
