@@ -285,8 +285,11 @@ def main():
         flops_per_launch = 2.0 * n_rows * (hi - lo) * DIM
         units_per_step = n_rows * (hi - lo)  # query x index pairs examined by this rank
 
+        # the index is static: it is wrapped once, with its squared norms, as the logo DB would be
+        index_cb = backend.make_codebook(index)
+
         def step():
-            return D.knn2_index_sharded(q, index, lo, 0.8, backend=backend)
+            return D.knn2_index_sharded(q, index_cb, lo, 0.8, backend=backend)
 
     def fence():
         torch.cuda.synchronize()
