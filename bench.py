@@ -6,12 +6,31 @@
 One step = one pass of the hot path over one batch of synthetic descriptors resident in HBM.
 The default workload is BASELINE config 2, "BoW quantisation + per-image L2-normalised histograms:
 1M descriptors x 10k-word codebook, 128-d": ic_assign_top1 over [1M,128] x [10k,128] followed by
-ic_hist (1000 images x 1000 descriptors, L2).  With N > 1 (launched by torch.distributed.run, one
-rank per GPU) every rank processes its own 1M descriptors -- the path shards by rows and needs no
-collective -- so scaling is weak and `value` is the sum over ranks.
+ic_hist (1000 images x 1000 descriptors, L2).
 
-The other workloads are the remaining BASELINE configs at their per-GPU size (they are parity /
-sizing cases run by hand, not the line the driver records):
+Ranks.  One process per GPU.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes
+this process a launcher: before it imports torch or touches a GPU it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, lets the ranks write
+to its stdout, and exits with the child's status.  Started by torch.distributed.run itself (the
+driver's form) the process is a rank and WORLD_SIZE must equal --gpus.  Every rank processes its
+own 1M descriptors -- the path shards by rows and needs no collective -- so scaling is weak and
+`value` is the sum over ranks divided by the slowest rank's time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA distance /
+top-2 kernel): algorithmic FLOPs per launch = 2 * N * K * D, divided by its average duration
+measured with HIP events recorded on the launch stream inside the timed region; `traffic` is that
+kernel's HBM bytes per launch from the newest profiles/*_<workload>_traffic.json (rocprofv3 --pmc
+FETCH_SIZE / WRITE_SIZE passes of that workload, read side doubled as gfx950 requires).
+`cpu_baseline` (rank 0, N == 1 only) times the call the reference makes -- scipy.cluster.vq.vq per
+image with a float64 vocabulary, then np.histogram -- on a bounded row sample of the same workload.
+`comm` (default workload only, outside the timed region) holds the two sub-paths that exchange
+data between ranks, each at its BASELINE size per GPU: `kmeans` (one Lloyd iteration of 1.25M rows
+x 65536 centroids with the all-reduce of sums + counts) and `knn` (4k queries against a 2M-row
+index split over the ranks, all-gather + merge of the per-rank top-2 records), with per-phase
+milliseconds (max over ranks).
+
+The other workloads are the remaining BASELINE configs at their per-GPU size (parity / sizing
+cases run by hand, not the line the driver records):
   knn     config 3: 4k queries vs a 2M-descriptor index split over N ranks, top-2 + ratio test,
           all-gather + merge of the per-rank records
   kmeans  config 4: one Lloyd iteration over 10M/8 rows, K = 65536, all-reduce of sums/counts
@@ -21,22 +40,17 @@ sizing cases run by hand, not the line the driver records):
           compacted per logo and verified by the batched homography RANSAC
   histknn the logo k-NN classifier's search: one query histogram vs 100 000 index histograms of
           10k bins, manhattan, 2 neighbours (HBM-bound: its roofline counts the index bytes)
-
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32-MFMA distance /
-top-2 kernel): algorithmic FLOPs per launch = 2 * N * K * D, divided by its average duration
-measured with HIP events recorded on the launch stream inside the timed region; `traffic` is that
-kernel's HBM bytes per launch from the newest profiles/*_<workload>_traffic.json (rocprofv3 --pmc
-FETCH_SIZE / WRITE_SIZE passes of that workload, read side doubled as gfx950 requires).  `cpu_baseline`
-(rank 0, N == 1 only) times the float64 numpy oracle on a bounded row sample of the same workload.
+  cfg1    config 1: 100k descriptors x 1k-word codebook (the case the reference runs on a CPU)
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -50,6 +64,9 @@ WORKLOADS = {
     "bow": dict(rows=1_000_000, k=10_000, images=1000, norm="l2",
                 name="BASELINE config 2: BoW quantisation + per-image L2 histograms, 1M descriptors "
                      "x 10k-word codebook x 128-d per GPU (1000 images x 1000 descriptors)"),
+    "cfg1": dict(rows=100_000, k=1000, images=100, norm="l1",
+                 name="BASELINE config 1: 100k descriptors x 1k-word codebook x 128-d, nearest "
+                      "codeword + per-image L1 histograms (100 images x 1000 descriptors)"),
     "video": dict(rows=4_000_000, k=10_000, images=2000, norm="power_l2",
                   name="BASELINE config 5 (per-GPU share): 2000 frames x 2000 descriptors, 10k words, "
                        "assignment + per-frame power/L2 histograms"),
@@ -69,51 +86,125 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(x_sample, codebook, per_image, norm):
-    """Oracle (numpy float64 restatement of scipy vq + np.histogram) on a row sample."""
+# ---------------------------------------------------------------------------------------------
+# launcher: the parent of N ranks.  Nothing here imports torch or touches a GPU.
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_command(n_ranks, argv, port=None):
+    """argv of the child that runs `n_ranks` ranks of this script on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(int(n_ranks)), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_ranks, argv):
+    """Start the ranks as a CHILD process (never exec: a launcher must stay a plain parent) and
+    pass its exit status on.  The ranks inherit stdout, so rank 0's JSON line appears here."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver supports dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n_ranks) // 2)))
+    return subprocess.call(rank_command(n_ranks, argv), env=env)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bow")
+    ap.add_argument("--codebook", type=int, default=0,
+                    help="override the workload's codebook size (bow / video / kmeans)")
+    ap.add_argument("--norm", default="", help="override the histogram norm (bow / video)")
+    ap.add_argument("--adverse", action="store_true",
+                    help="bow / video / cfg1: order the codebook by descending distance to the "
+                         "data mean, so that later codewords keep improving the running top-2 "
+                         "(the worst case for the kernel's ranking gate)")
+    ap.add_argument("--cpu-sample", type=int, default=400_000,
+                    help="rows of the workload the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--no-comm", action="store_true",
+                    help="skip the k-means / index-sharded 2-NN sub-records of the default workload")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (smoke test)")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="'gloo' lets several ranks share one GPU to rehearse the multi-rank code "
+                         "path on a one-GPU box (RCCL refuses two ranks on one device)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="ranks only rendezvous over gloo on the CPU and report themselves "
+                         "(tests the launcher where there is no GPU)")
+    ap.add_argument("--comm-timeout", type=float, default=240.0,
+                    help="seconds after which rank 0 prints the line without the comm records")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(x_sample, codebook32, per_image, norm):
+    """The reference's CPU path on a row sample, timed on this box's host cores.
+
+    `value`: scipy.cluster.vq.vq per image (float32 descriptors, float64 vocabulary: the dtypes of
+    model/features.py:1166, :1335-1341) followed by np.histogram and the normalisation
+    (:1174-1181), on all BLAS threads; `one_core_value` the same on one thread.  `port_value` is
+    the float64 numpy restatement the parity tests use, `sklearn_argmin_value` the batched
+    euclidean_distances + argmin of vision/utils/scene_functions.py:385-392."""
+    import numpy as np
     import oracle
+    from oracle import reference_calls as ref
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_info, threadpool_limits
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+        threadpool_limits = None
+        blas_threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    vocab64 = codebook32.astype(np.float64)
+    n = x_sample.shape[0]
+    n_img = n // per_image
+    images = [x_sample[i * per_image:(i + 1) * per_image] for i in range(n_img)]
     t0 = time.perf_counter()
-    code, _ = oracle.vq(x_sample, codebook)
-    n_img = x_sample.shape[0] // per_image
-    oracle.build_histogram([code[i * per_image:(i + 1) * per_image] for i in range(n_img)],
-                           codebook.shape[0], norm)
+    codes, _h = ref.bow_quantize(images, vocab64, norm)
     dt = time.perf_counter() - t0
-    one_core = None
-    try:   # the same restatement on one BLAS thread, on a tenth of the sample
-        from threadpoolctl import threadpool_limits
-        ns1 = max(per_image, x_sample.shape[0] // 10 // per_image * per_image)
+    code = np.concatenate(codes)
+    one_core = dt1 = None
+    if threadpool_limits is not None:
         with threadpool_limits(limits=1):
             t1 = time.perf_counter()
-            oracle.vq(x_sample[:ns1], codebook)
-            one_core = ns1 / (time.perf_counter() - t1)
-    except Exception:
-        pass
-    scipy_value = scipy_agree = None
-    try:   # the library call the reference itself makes (model/features.py:1166), where installed
-        from scipy.cluster.vq import vq as scipy_vq
-        ns2 = max(per_image, x_sample.shape[0] // 10 // per_image * per_image)
-        xs, cs = x_sample[:ns2].astype(np.float64), codebook.astype(np.float64)
-        t2 = time.perf_counter()
-        sc_code, _ = scipy_vq(xs, cs)
-        scipy_value = ns2 / (time.perf_counter() - t2)
-        scipy_agree = float(np.mean(sc_code == code[:ns2]))
-    except ImportError:
-        pass
-    return {"value": x_sample.shape[0] / dt, "unit": "assignments/s", "cores": int(cores),
-            "kind": "port", "one_core_value": one_core, "scipy_vq_value": scipy_value,
-            "scipy_vq_agreement_with_port": scipy_agree,
-            "sample": "%d rows of the workload (same codebook; float64 numpy GEMM + argmin + "
-                      "np.histogram), %.1f s" % (x_sample.shape[0], dt)}, code
+            ref.bow_quantize(images, vocab64, norm)
+            dt1 = time.perf_counter() - t1
+            one_core = n / dt1
+    ns = max(per_image, n // 4 // per_image * per_image)
+    t2 = time.perf_counter()
+    pcode, _ = oracle.vq(x_sample[:ns], codebook32)
+    oracle.build_histogram([pcode[i * per_image:(i + 1) * per_image] for i in range(ns // per_image)],
+                           codebook32.shape[0], norm)
+    port_value = ns / (time.perf_counter() - t2)
+    t3 = time.perf_counter()
+    scode = ref.compute_vocab_features(codebook32, x_sample[:ns])
+    sk_value = ns / (time.perf_counter() - t3) if scode is not None else None
+    return {"value": n / dt, "unit": "assignments/s", "cores": int(blas_threads),
+            "kind": "reference", "one_core_value": one_core,
+            "host_cpus": os.cpu_count(), "blas_threads": int(blas_threads),
+            "port_value": port_value,
+            "port_agreement_with_reference": float(np.mean(pcode == code[:ns])),
+            "sklearn_argmin_value": sk_value,
+            "sklearn_agreement_with_reference":
+                float(np.mean(scode == code[:ns])) if scode is not None else None,
+            "libraries": ref.versions(),
+            "sample": "%d rows = %d images of the workload, same vocabulary: the reference's own "
+                      "calls (scipy.cluster.vq.vq per image, float32 rows / float64 vocabulary, "
+                      "+ np.histogram + %s norm; the reference's Python 2 modules cannot be "
+                      "imported), %.1f s on %d BLAS threads%s; port and sklearn legs on the first "
+                      "%d rows" % (n, n_img, norm, dt, blas_threads,
+                                   ", %.1f s on one" % dt1 if dt1 else "", ns)}, code
 
 
 def cpu_baseline_logo(x, kp_rows, q, kp_q, per, n_logos, n_iter, gpu_inliers, gpu_off):
     """Oracle restatement of the reference's per-logo loop (2-NN + ratio test + its own ransac())
     on the first `n_logos` logo images; reports rows/s and how often accept/reject agrees."""
+    import numpy as np
     import oracle
     from oracle import ransac_ref
     rows = n_logos * per
@@ -156,30 +247,193 @@ def measured_traffic(workload, kernel="k_top2_partial"):
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bow")
-    ap.add_argument("--codebook", type=int, default=0,
-                    help="override the workload's codebook size (bow / video / kmeans)")
-    ap.add_argument("--norm", default="", help="override the histogram norm (bow / video)")
-    ap.add_argument("--cpu-sample", type=int, default=400_000,
-                    help="rows of the workload the CPU oracle is timed on (0 = skip)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the RCCL process group even with one rank (smoke test)")
-    ap.add_argument("--dist-backend", default="nccl",
-                    help="'gloo' lets several ranks share one GPU to rehearse the multi-rank code "
-                         "path on a one-GPU box (RCCL refuses two ranks on one device)")
-    args = ap.parse_args()
+def adverse_order(cb, x):
+    """Codebook rows by DESCENDING distance to the mean descriptor: scanning in index order, the
+    candidates keep getting nearer, so tiles keep passing the ranking gate."""
+    import torch
+    mean = x[: min(x.shape[0], 200_000)].mean(0, keepdim=True)
+    d = torch.cdist(cb, mean).reshape(-1)
+    return cb[torch.argsort(d, descending=True)].contiguous()
 
+
+# ---------------------------------------------------------------------------------------------
+class Fence(object):
+    """Device synchronisation + barrier over the ranks, and max-over-ranks of host timings."""
+
+    def __init__(self, torch, dist, use_dist, dev, backend_name):
+        self.torch, self.dist, self.use_dist = torch, dist, use_dist
+        self.red_dev = dev if backend_name == "nccl" else "cpu"
+
+    def __call__(self):
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64,
+                              device=self.red_dev)
+        if self.use_dist:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+
+def kmeans_phases(torch, fence, D, backend, x, c0, labels0, allreduce, iters):
+    """`iters` Lloyd iterations with the device synchronised (and the ranks aligned) between the
+    phases: milliseconds per phase, averaged over the iterations, max over ranks."""
+    k, d = c0.shape
+    tot = {"assign_ms": 0.0, "centroid_sums_ms": 0.0, "allreduce_ms": 0.0, "finalize_ms": 0.0}
+
+    def timed(name, fn):
+        fence()
+        t_a = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        tot[name] += (time.perf_counter() - t_a) * 1e3
+        return r
+
+    c, labels = c0, labels0
+    for _ in range(iters):
+        cbk = backend.make_codebook(c)
+        labels, _ = timed("assign_ms", lambda: backend.assign_top1(x, cbk, want_dist=False,
+                                                                   hint=labels))
+        out = allreduce.outputs(k, d, x.device) if allreduce is not None else None
+        sums, counts = timed("centroid_sums_ms",
+                             lambda: backend.centroid_partials(x, labels, k, out=out))
+        if allreduce is not None:
+            timed("allreduce_ms", lambda: allreduce(sums, counts))
+        c, _has = timed("finalize_ms", lambda: backend.centroid_finalize(sums, counts, c))
+    names = sorted(tot)
+    vals = fence.max_over_ranks([tot[n] / iters for n in names])
+    return dict(zip(names, vals)), c, labels
+
+
+def comm_records(torch, dist, fence, D, backend, dev, rank, world, use_dist, dist_backend):
+    """The two sub-paths that exchange data between ranks, each at its BASELINE per-GPU size."""
+    from image_classification_amd.synthetic import sift_like_device
+    out = {}
+    # -- k-means (config 4 share): rows sharded, all-reduce of the packed sums + counts ----------
+    rows, k = WORKLOADS["kmeans"]["rows"], WORKLOADS["kmeans"]["k"]
+    x = sift_like_device(rows, DIM, n_modes=4096, seed=7 + 1000 * rank, device=dev)
+    c0 = sift_like_device(k, DIM, n_modes=4096, seed=8, device=dev)
+    allreduce = D.make_allreduce() if use_dist else None
+    c, labels, _ = D.lloyd(x, c0, 1, backend, allreduce=allreduce)            # warm-up iteration
+    iters = 3
+    fence()
+    t0 = time.perf_counter()
+    c, labels, _ = D.lloyd(x, c, iters, backend, allreduce=allreduce, labels0=labels)
+    fence()
+    (dt,) = fence.max_over_ranks([time.perf_counter() - t0])
+    phases, c, labels = kmeans_phases(torch, fence, D, backend, x, c, labels, allreduce, 2)
+    identical = True
+    if use_dist:
+        chk = torch.stack([c.double().sum(), c.double().abs().max()]).to(fence.red_dev)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        identical = bool(torch.equal(lo, hi))
+    out["kmeans"] = {
+        "workload": WORKLOADS["kmeans"]["name"], "rows_per_gpu": rows, "centroids": k,
+        "ranks": world, "iterations_timed": iters, "ms_per_iteration": dt / iters * 1e3,
+        "assignments_per_s": world * rows * iters / dt,
+        "allreduce_bytes": (k * DIM + k) * 8 if use_dist else 0,
+        "collective": ("%s all_reduce(sum) of one packed float64 buffer" % dist_backend)
+        if use_dist else "none (one rank)",
+        "centroids_identical_on_all_ranks": identical, "phase_ms": phases}
+    del x, c0, c, labels, allreduce
+    torch.cuda.empty_cache()
+
+    # -- 2-NN with the index sharded (config 3): all-gather of 16-byte records + merge ------------
+    nq, total = WORKLOADS["knn"]["rows"], WORKLOADS["knn"]["k"]
+    bounds = D.shard_bounds(total, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    index = sift_like_device(hi - lo, DIM, n_modes=4096, seed=6 + 1000 * rank, device=dev)
+    q = sift_like_device(nq, DIM, n_modes=4096, seed=5, device=dev)
+    index_cb = backend.make_codebook(index)
+    for _ in range(2):
+        res = D.knn2_index_sharded(q, index_cb, lo, 0.8, backend=backend)
+    iters = 10
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        res = D.knn2_index_sharded(q, index_cb, lo, 0.8, backend=backend)
+    fence()
+    (dt,) = fence.max_over_ranks([time.perf_counter() - t0])
+    tot = {"search_ms": 0.0, "allgather_ms": 0.0, "merge_ms": 0.0}
+
+    def timed(name, fn):
+        fence()
+        t_a = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        tot[name] += (time.perf_counter() - t_a) * 1e3
+        return r
+
+    reps = 3
+    for _ in range(reps):
+        rec = timed("search_ms", lambda: backend.assign_top2_rec(q, index_cb))
+        gathered, bases = timed("allgather_ms", lambda: D.gather_records(rec, lo))
+        timed("merge_ms", lambda: backend.top2_merge(gathered, bases, 0.8))
+    names = sorted(tot)
+    vals = fence.max_over_ranks([tot[n] / reps for n in names])
+    same = True
+    if use_dist:
+        chk = torch.stack([res[0].double().sum(), res[2].double().sum()]).to(fence.red_dev)
+        a, b = chk.clone(), chk.clone()
+        dist.all_reduce(a, op=dist.ReduceOp.MIN)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(a, b))
+    out["knn"] = {
+        "workload": WORKLOADS["knn"]["name"], "queries": nq, "index_rows_total": total,
+        "index_rows_per_gpu": hi - lo, "ranks": world, "ms_per_search": dt / iters * 1e3,
+        "pairs_per_s": float(nq) * total * iters / dt,
+        "allgather_bytes_per_rank": nq * 16 if use_dist else 0,
+        "collective": ("%s all_gather_into_tensor of the per-rank records + top-2 merge"
+                       % dist_backend) if use_dist else "none (one rank)",
+        "result_identical_on_all_ranks": same, "phase_ms": dict(zip(names, vals))}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def launch_check(args):
+    """Ranks rendezvous over gloo on the CPU and rank 0 reports who came: the launcher's test."""
     import torch
     import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    pids = [os.getpid()]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = os.getpid()
+        dist.all_reduce(t)
+        pids = [int(v) for v in t]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "requested": args.gpus,
+                          "rank_pids": pids, "launcher_pid": os.getppid()}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: start the ranks with "
+                         "`python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d` "
+                         "or let `python bench.py --gpus %d` do it\n"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+        return 2
+    if args.launch_check:
+        return launch_check(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     if args.dist_backend != "nccl":
@@ -194,6 +448,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from image_classification_amd import distributed as D
     from image_classification_amd import ops
@@ -208,19 +463,24 @@ def main():
         w["norm"] = args.norm
         w["name"] += " [norm overridden: %s]" % args.norm
     backend = HipBackend(dev)
+    fence = Fence(torch, dist, use_dist, dev, args.dist_backend)
     n_rows, k_words = w["rows"], w["k"]
     flops_per_launch = None
     units_per_step = n_rows  # what `value` counts per rank and step
+    quantising = args.workload in ("bow", "video", "cfg1")
 
-    if args.workload in ("bow", "video"):
+    if quantising:
         cb = sift_like_device(k_words, DIM, n_modes=2048, seed=4, device=dev)
         x = sift_like_device(n_rows, DIM, n_modes=2048, seed=3 + 1000 * rank, device=dev)
+        if args.adverse:
+            cb = adverse_order(cb, x)
+            w["name"] += " [codebook in adverse order: descending distance to the data mean]"
         offsets = torch.from_numpy(image_offsets(w["images"], n_rows // w["images"])).to(dev)
-        cn = ops.row_sqnorm(cb)
+        cbk = backend.make_codebook(cb)
         flops_per_launch = 2.0 * n_rows * k_words * DIM
 
         def step():
-            idx, _ = ops.assign_top1(x, cb, cn, want_dist=False)
+            idx, _ = backend.assign_top1(x, cbk, want_dist=False)
             return idx, ops.hist(idx, offsets, k_words, w["norm"])
     elif args.workload == "kmeans":
         x = sift_like_device(n_rows, DIM, n_modes=4096, seed=7 + 1000 * rank, device=dev)
@@ -255,12 +515,12 @@ def main():
         kp_rows[rows] = t[:, :2] / t[:, 2:] + 0.3 * torch.randn((rows.numel(), 2), dtype=torch.float64,
                                                                 device=dev, generator=g)
         row_off = torch.from_numpy(image_offsets(n_img, per)).to(dev)
-        cn = ops.row_sqnorm(q)
+        qcb = backend.make_codebook(q)
         flops_per_launch = 2.0 * n_rows * k_words * DIM
         n_iter = 46   # int(log(1 - 0.95) / log(1 - 0.5 ** 4)), the reference's defaults
 
         def step():
-            i1, _d1, _i2, _d2, mask = ops.assign_top2(x, q, 0.8, cn)
+            i1, _d1, _i2, _d2, mask = backend.assign_top2(x, qcb, 0.8)
             out_off, mq, mi, pts = ops.compact_matches(mask, i1, row_off, kp_q, kp_rows)
             res = ops.ransac_homography(pts, out_off, n_iter, 3.0, None, 1, 10, True)
             return res[1], out_off
@@ -291,12 +551,6 @@ def main():
         def step():
             return D.knn2_index_sharded(q, index_cb, lo, 0.8, backend=backend)
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     fence()
@@ -307,31 +561,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kern_ms, launches = ops.profile_end(local_rank)
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    (dt_max,) = fence.max_over_ranks([dt])
 
     phases = None
-    if args.workload == "kmeans" and rank == 0:
-        # one more iteration with a device synchronisation between its phases
-        def timed(fn):
-            torch.cuda.synchronize()
-            t_a = time.perf_counter()
-            r = fn()
-            torch.cuda.synchronize()
-            return r, (time.perf_counter() - t_a) * 1e3
-        cbk = backend.make_codebook(state["c"])
-        (lab, _), t_assign = timed(lambda: backend.assign_top1(x, cbk, want_dist=False))
-        (sums, counts), t_part = timed(lambda: backend.centroid_partials(x, lab, k_words))
-        t_red = 0.0
-        if allreduce is not None and args.dist_backend == "nccl" and world == 1:
-            _, t_red = timed(lambda: allreduce(sums, counts))
-        _, t_fin = timed(lambda: backend.centroid_finalize(sums, counts, state["c"]))
-        phases = {"assign_ms": t_assign, "centroid_sums_ms": t_part, "allreduce_ms": t_red,
-                  "finalize_ms": t_fin}
+    if args.workload == "kmeans":
+        phases, _c, _l = kmeans_phases(torch, fence, D, backend, x, state["c"], state["labels"],
+                                       allreduce, 2)
 
+    out = None
     if rank == 0:
         props = torch.cuda.get_device_properties(dev)
         value = world * units_per_step * args.steps / dt_max
@@ -347,11 +584,27 @@ def main():
                         "bytes_per_launch": bytes_per_launch}
         else:
             achieved = flops_per_launch / avg_kernel_s / 1e12
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                        "traffic": measured_traffic(args.workload),
+                        "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
+                        "flops_per_launch": flops_per_launch,
+                        "peak_basis": "256 CU x 256 FLOP/clk x 2.4 GHz; this device reports "
+                                      "%d CUs%s" % (props.multi_processor_count,
+                                                    " at %.0f MHz" % (props.clock_rate / 1e3)
+                                                    if hasattr(props, "clock_rate") else "")}
         metric, unit = ("descriptor->codeword assignments/sec", "assignments/s")
         if is_pairs:
             metric, unit = ("query-index descriptor pairs examined/sec", "pairs/s")
         if is_hist:
             metric, unit = ("index histograms compared/sec", "histograms/s")
+        parallelism = {"bow": "rows sharded, no collective",
+                       "cfg1": "rows sharded, no collective",
+                       "video": "frames sharded, no collective",
+                       "logo": "logo images sharded, no collective",
+                       "kmeans": "rows sharded, RCCL all-reduce of sums+counts per iteration",
+                       "histknn": "replicas (index rows would shard, top-k merge)",
+                       "knn": "index sharded, RCCL all-gather + top-2 merge"}[args.workload]
         out = {
             "metric": metric,
             "value": value,
@@ -368,23 +621,13 @@ def main():
             "config": {"workload": w["name"], "rows_per_gpu": n_rows,
                        "codebook": k_words if not is_pairs else int(flops_per_launch / (2.0 * n_rows * DIM)),
                        "dim": k_words if is_hist else DIM,
-                       "parallelism": {"bow": "rows sharded, no collective",
-                                       "video": "frames sharded, no collective",
-                                       "logo": "logo images sharded, no collective",
-                                       "kmeans": "rows sharded, RCCL all-reduce of sums+counts per iteration",
-                                       "histknn": "replicas (index rows would shard, top-k merge)",
-                                       "knn": "index sharded, RCCL all-gather + top-2 merge"}[args.workload]},
-            "roofline": roofline if is_hist else {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": measured_traffic(args.workload),
-                         "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "flops_per_launch": flops_per_launch,
-                         "peak_basis": "256 CU x 256 FLOP/clk x 2.4 GHz; this device reports "
-                                       "%d CUs%s" % (props.multi_processor_count,
-                                                     " at %.0f MHz" % (props.clock_rate / 1e3)
-                                                     if hasattr(props, "clock_rate") else "")},
+                       "parallelism": parallelism,
+                       "ranks": world,
+                       "rccl_ranks": dist.get_world_size() if use_dist and args.dist_backend == "nccl" else 0,
+                       "dist_backend": args.dist_backend if use_dist else None},
+            "roofline": roofline,
         }
-        if world == 1 and args.cpu_sample > 0 and args.workload in ("bow", "video"):
+        if world == 1 and args.cpu_sample > 0 and quantising:
             per_image = n_rows // w["images"]
             ns = min(args.cpu_sample, n_rows)
             ns -= ns % per_image
@@ -393,24 +636,76 @@ def main():
             out["cpu_baseline"] = base
         if phases is not None:
             out["config"]["phase_ms"] = phases
-        if args.workload in ("bow", "video") and args.cpu_sample > 0:
+        if quantising and args.cpu_sample > 0:
             # every row of the workload against the direct float32 search on the device (no norm
             # expansion; outside the timed region)
             e1, ed1, _e2, ed2, _m = ops.assign_top2_exact(x, cb)
             gap = (ed2 - ed1) > 1e-5 * ed1
             out["parity"] = {"checked_rows": int(n_rows), "checker": "direct float32 search on the device",
                              "agreement": float((out_a == e1).float().mean()),
+                             "mismatches": int((out_a != e1).sum()),
                              "mismatches_where_gap_exceeds_1e-5": int(((out_a != e1) & gap).sum())}
         if world == 1 and args.cpu_sample > 0 and args.workload == "logo":
             out["cpu_baseline"] = cpu_baseline_logo(
                 x, kp_rows, q, kp_q, per, max(1, min(n_img, args.cpu_sample // per // 2)), n_iter,
                 out_a, out_b)
+        if world == 1 and args.cpu_sample > 0 and is_pairs:
+            # measured agreement of the index-sharded search with the float64 oracle on a sample
+            import oracle
+            nq_s, ni_s = 500, 200_000
+            i1s, d1s, i2s, _d2s, _ms = D.knn2_index_sharded(q[:nq_s], index[:ni_s], 0, 0.8,
+                                                            backend=backend)
+            rd, ri = oracle.topk(q[:nq_s].cpu().numpy(), index[:ni_s].cpu().numpy(), 3)
+            must1, bad1, agree1 = oracle.check_indices(i1s.cpu().numpy(), ri, rd, 0)
+            must2, bad2, agree2 = oracle.check_indices(i2s.cpu().numpy(), ri, rd, 1)
+            out["parity"] = {"checker": "float64 oracle, %d queries x %d index rows" % (nq_s, ni_s),
+                             "agreement_nearest": agree1, "agreement_second": agree2,
+                             "must_match_rows": [must1, must2],
+                             "mismatches_where_gap_exceeds_1e-5": [bad1, bad2],
+                             "max_rel_distance_error": oracle.check_close(d1s.cpu().numpy(), rd[:, 0])}
+
+    if args.workload == "bow" and not args.no_comm and not args.adverse:
+        # free the headline workload's buffers, then the two communicating sub-paths; should they
+        # not finish in time, rank 0 still prints the line it has
+        def give_up():
+            if rank == 0 and out is not None:
+                out["comm"] = {"error": "sub-records did not finish within %.0f s" % args.comm_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.comm_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            del x, out_a, out_b
+            torch.cuda.empty_cache()
+            comm = comm_records(torch, dist, fence, D, backend, dev, rank, world, use_dist,
+                                args.dist_backend)
+        except Exception as e:   # the headline line must survive a failing sub-record
+            comm = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+        if out is not None:
+            out["comm"] = comm
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be at least 1\n")
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -92,8 +92,8 @@ class HipBackend(object):
     def spatial_hist(self, codes, kp_cells, cell_weights, k):
         return ops.spatial_hist(codes, kp_cells, cell_weights, k)
 
-    def centroid_partials(self, x, codes, k):
-        return ops.centroid_partials(x, codes, k)
+    def centroid_partials(self, x, codes, k, out=None):
+        return ops.centroid_partials(x, codes, k, out=out)
 
     def centroid_finalize(self, sums, counts, prev_c):
         return ops.centroid_finalize(sums, counts, prev_c)

@@ -46,7 +46,12 @@ def lloyd(xd, c0, iters, backend, allreduce=None, on_empty=None, labels0=None):
         # the labels of the previous iteration are a guess of the new ones: same result, and the
         # search skips ranking candidates that cannot beat the guessed centroid
         labels, _dist = backend.assign_top1(xd, cb, want_dist=False, hint=labels)
-        sums, counts = backend.centroid_partials(xd, labels, k)
+        if hasattr(allreduce, "outputs"):
+            # the collective's own buffer receives the sums: nothing is copied before the exchange
+            sums, counts = backend.centroid_partials(xd, labels, k,
+                                                     out=allreduce.outputs(k, c0.shape[1], xd.device))
+        else:
+            sums, counts = backend.centroid_partials(xd, labels, k)
         if allreduce is not None:
             allreduce(sums, counts)
         new_c, has = backend.centroid_finalize(sums, counts, cb.c)

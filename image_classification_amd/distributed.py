@@ -127,17 +127,44 @@ def gather_rows(t, group=None):
     return [flat[r * m:r * m + s] for r, s in enumerate(sizes)]
 
 
-def make_allreduce(group=None):
-    """In-place sum over ranks of (sums float64 [k,d], counts int64 [k]) as ONE packed buffer."""
-    def allreduce(sums, counts):
+class PackedAllReduce(object):
+    """In-place sum over ranks of (sums float64 [k,d], counts int64 [k]) as ONE float64 buffer.
+
+    The buffer lives as long as this object: `outputs(k, d, device)` hands out the views the
+    centroid-sum kernel writes into, so an iteration moves no copy of the sums (67 MB at
+    k = 65536) -- only the k counts are converted (exact below 2^53 members) into the buffer's
+    tail before the collective and back after it."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._buf = None
+        self._key = None
+
+    def outputs(self, k, d, device):
+        key = (int(k), int(d), str(device))
+        if self._key != key:
+            self._buf = torch.empty(k * d + k, dtype=torch.float64, device=device)
+            self._counts = torch.empty(k, dtype=torch.int64, device=device)
+            self._key = key
+        return self._buf[:k * d].view(k, d), self._counts
+
+    def __call__(self, sums, counts):
         k, d = sums.shape
-        buf = torch.empty(k * d + k, dtype=torch.float64, device=sums.device)
-        buf[:k * d] = sums.reshape(-1)
-        buf[k * d:] = counts.to(torch.float64)      # exact below 2^53 members
-        _all_reduce(buf, group)
-        sums.copy_(buf[:k * d].reshape(k, d))
-        counts.copy_(buf[k * d:].round().to(torch.int64))
-    return allreduce
+        mine = self._buf is not None and self._key[:2] == (k, d) \
+            and sums.data_ptr() == self._buf.data_ptr()
+        if not mine:                                   # sums produced elsewhere: copy in and out
+            own_sums, _ = self.outputs(k, d, sums.device)
+            own_sums.copy_(sums)
+        tail = self._buf[k * d:]
+        tail.copy_(counts)                             # int64 -> float64
+        _all_reduce(self._buf, self.group)
+        counts.copy_(tail.round().to(torch.int64))
+        if not mine:
+            sums.copy_(self._buf[:k * d].view(k, d))
+
+
+def make_allreduce(group=None):
+    return PackedAllReduce(group)
 
 
 def kmeans_fit_sharded(x_local, init, iters, backend=None, group=None, on_empty=None):
@@ -157,6 +184,21 @@ def kmeans_fit_sharded(x_local, init, iters, backend=None, group=None, on_empty=
                  on_empty=on_empty)
 
 
+def gather_records(rec, index_base, group=None):
+    """All-gather every rank's per-row records [n, 4] (int32 words of ic_top2_rec) into
+    [n_ranks, n, 4], and the ranks' index bases into a list of ints."""
+    rank, n = world(group)
+    if n == 1:
+        return rec.unsqueeze(0).contiguous(), [int(index_base)]
+    rows = rec.shape[0]
+    flat = torch.empty((n * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    _all_gather_into(flat, rec, group)                # rank r -> rows [r*rows, (r+1)*rows)
+    bases = torch.zeros(n, dtype=torch.int64, device=rec.device)
+    bases[rank] = int(index_base)
+    _all_reduce(bases, group)
+    return flat.view(n, rows, rec.shape[1]), [int(v) for v in bases.cpu()]
+
+
 def knn2_index_sharded(queries, index_local, index_base, ratio=0.8, backend=None, group=None):
     """Two nearest index rows of every query when the index is split over ranks.
 
@@ -164,18 +206,9 @@ def knn2_index_sharded(queries, index_local, index_base, ratio=0.8, backend=None
     of its first row.  Returns (i1 int64, d1, i2 int64, d2, mask) identical on every rank.
     """
     b = backend or default_backend()
-    rank, n = world(group)
     rec = b.assign_top2_rec(b.f32(queries), b.codebook(index_local))
-    if n == 1:
-        return b.top2_merge(rec.unsqueeze(0).contiguous(), [int(index_base)], ratio)
-    rows = rec.shape[0]
-    flat = torch.empty((n * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
-    _all_gather_into(flat, rec, group)                # rank r -> rows [r*rows, (r+1)*rows)
-    gathered = flat.view(n, rows, rec.shape[1])
-    bases = torch.zeros(n, dtype=torch.int64, device=rec.device)
-    bases[rank] = int(index_base)
-    _all_reduce(bases, group)
-    return b.top2_merge(gathered, [int(v) for v in bases.cpu()], ratio)
+    gathered, bases = gather_records(rec, index_base, group)
+    return b.top2_merge(gathered, bases, ratio)
 
 
 def knn2_rows_sharded(index, rows_local, ratio=0.8, backend=None, gather=False, group=None):

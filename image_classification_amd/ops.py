@@ -438,14 +438,23 @@ def spatial_hist(codes, kp_cells, cell_weights, k):
     return out
 
 
-def centroid_partials(x, codes, k):
-    """sums float64 [k, d] and counts int64 [k] of the rows of x grouped by code."""
+def centroid_partials(x, codes, k, out=None):
+    """sums float64 [k, d] and counts int64 [k] of the rows of x grouped by code.
+    `out` = (sums, counts) preallocated contiguous device tensors (views are fine)."""
     _check_2d_f32(x, "x")
     if codes.dtype != torch.int32 or codes.shape[0] != x.shape[0]:
         raise ValueError("codes must be int32 with one entry per row of x")
     dev = _dev_index(x)
-    sums = torch.empty((int(k), x.shape[1]), dtype=torch.float64, device=x.device)
-    counts = torch.empty(int(k), dtype=torch.int64, device=x.device)
+    if out is not None:
+        sums, counts = out
+        if (sums.dtype != torch.float64 or tuple(sums.shape) != (int(k), x.shape[1])
+                or counts.dtype != torch.int64 or tuple(counts.shape) != (int(k),)
+                or not sums.is_contiguous() or not counts.is_contiguous()
+                or sums.device != x.device or counts.device != x.device):
+            raise ValueError("out must be (float64 [k, d], int64 [k]) contiguous on x's device")
+    else:
+        sums = torch.empty((int(k), x.shape[1]), dtype=torch.float64, device=x.device)
+        counts = torch.empty(int(k), dtype=torch.int64, device=x.device)
     rc = _lib.load().ic_centroid_partials(_lib.handle(dev), _ptr(x), _ptr(codes.contiguous()),
                                           x.shape[0], int(k), x.shape[1], _ptr(sums), _ptr(counts),
                                           _stream_ptr(dev))

@@ -123,9 +123,14 @@ class CheckerBackend(object):
         out *= w[None, :, None]
         return torch.from_numpy(out.reshape(c.shape[0], -1))
 
-    def centroid_partials(self, x, codes, k):
+    def centroid_partials(self, x, codes, k, out=None):
         _, _, sums, counts = oracle.update_cluster_means(x.numpy(), codes.numpy().astype(np.int64), int(k))
-        return torch.from_numpy(sums), torch.from_numpy(counts.astype(np.int64))
+        sums, counts = torch.from_numpy(sums), torch.from_numpy(counts.astype(np.int64))
+        if out is not None:
+            out[0].copy_(sums)
+            out[1].copy_(counts)
+            return out
+        return sums, counts
 
     def centroid_finalize(self, sums, counts, prev_c):
         has = counts > 0
