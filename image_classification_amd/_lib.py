@@ -39,6 +39,7 @@ _SIGNATURES = {
     "ic_profile_end": [_p, ctypes.POINTER(_c_d), ctypes.POINTER(_c_i64)],
     "ic_row_sqnorm": [_p, _p, _c_i64, _c_int, _p, _p],
     "ic_assign_top1": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
+    "ic_assign_top1_static": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
     "ic_assign_top1_hint": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _p],
     "ic_assign_top2": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _p, _c_f, _p, _p],
     "ic_assign_top2_exact": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _c_f, _p, _p],

@@ -1,5 +1,6 @@
 // C ABI of libic_hip.so (declared in include/ic_hip.h): handle, workspace, argument checks and the
-// launch sequences.  No kernel lives here.
+// launch sequences.  No kernel lives here; the one device symbol is the static scratch buffer of
+// the entry point that allocates nothing.
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +32,13 @@ int fail_hip(hipError_t e, const char* what) {
 
 constexpr uint64_t kMagic = 0x1c41ffa5d15c0de5ULL;
 
+// Scratch of ic_assign_top1_static: device memory that exists from the moment the code object is
+// loaded, one copy per GPU, so that entry point never has to allocate.  In host code the name
+// `scratch` is only a handle for hipGetSymbolAddress (ic_create asks once per device and keeps the
+// answer in the handle); every launch receives that address as an ordinary argument.
+constexpr size_t kStaticScratchBytes = IC_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 struct Ctx {
   uint64_t magic = kMagic;
   int device = 0;
@@ -38,6 +46,7 @@ struct Ctx {
   std::mutex mu;
   char* ws = nullptr;
   size_t ws_bytes = 0;
+  char* static_scratch = nullptr;  // this device's address of `scratch`
   hipEvent_t done = nullptr;      // recorded after each call's last launch
   hipStream_t last_stream = nullptr;
   bool have_last = false;
@@ -145,7 +154,7 @@ int profile_open(Ctx* c, hipStream_t s, hipEvent_t* stop) {
 int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                 const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
                 uint8_t* mask, ic_top2_rec* rec, void* stream, const char* who,
-                const int32_t* hint = nullptr) {
+                const int32_t* hint = nullptr, bool use_static = false) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "%s: invalid handle", who);
   if (n < 0 || k < 1 || k > 0x7fffffffLL) return fail(IC_EINVAL, "%s: need n >= 0 and 1 <= k < 2^31 (n=%lld k=%lld)", who, (long long)n, (long long)k);
@@ -162,26 +171,38 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   const int64_t kpad = (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
   ic::AssignPlan plan;
   ic::assign_plan(n, k, ctx->num_cus, &plan);
-  const int nsplit = plan.nsplit;
   const bool pad = d != ic::kD;
   size_t off = 0;
   const size_t o_cn = off;   off += align_up((size_t)kpad * 4);
-  const size_t o_part = off; off += align_up((size_t)nsplit * (size_t)n * sizeof(ic_top2_rec));
+  const size_t o_part = off;
+  off += align_up((size_t)ic::assign_part_records(plan, n) * sizeof(ic_top2_rec));
   const size_t o_xp = off;   if (pad) off += align_up((size_t)n * ic::kD * 4);
   const size_t o_cp = off;   if (pad) off += align_up((size_t)k * ic::kD * 4);
   const size_t o_thr = off;  if (hint) off += align_up((size_t)n * 4);
-  int rc = ensure_ws(ctx, off);
-  if (rc) return rc;
-  rc = order_after_previous(ctx, s);
-  if (rc) return rc;
+  int rc;
+  char* ws;
+  if (use_static) {
+    // no allocation, no event, nothing but launches on the caller's stream
+    if (off > kStaticScratchBytes)
+      return fail(IC_ELIMIT, "%s: n=%lld k=%lld d=%d needs %zu bytes of scratch, the static buffer "
+                  "holds %zu; use the allocating entry point", who, (long long)n, (long long)k, d,
+                  off, kStaticScratchBytes);
+    ws = ctx->static_scratch;
+  } else {
+    rc = ensure_ws(ctx, off);
+    if (rc) return rc;
+    rc = order_after_previous(ctx, s);
+    if (rc) return rc;
+    ws = ctx->ws;
+  }
 
-  float* cn = reinterpret_cast<float*>(ctx->ws + o_cn);
-  ic_top2_rec* part = reinterpret_cast<ic_top2_rec*>(ctx->ws + o_part);
+  float* cn = reinterpret_cast<float*>(ws + o_cn);
+  ic_top2_rec* part = reinterpret_cast<ic_top2_rec*>(ws + o_part);
   const float* xs = x;
   const float* cs = c;
   if (pad) {
-    float* xp = reinterpret_cast<float*>(ctx->ws + o_xp);
-    float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
+    float* xp = reinterpret_cast<float*>(ws + o_xp);
+    float* cp = reinterpret_cast<float*>(ws + o_cp);
     IC_HIP(ic::launch_pad_rows(x, n, d, xp, s), "pad descriptors");
     IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
     xs = xp;
@@ -190,17 +211,19 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   IC_HIP(ic::launch_codebook_norms(cs, k, kpad, c_sqnorm, cn, s), "codebook norms");
   float* thr = nullptr;
   if (hint) {
-    thr = reinterpret_cast<float*>(ctx->ws + o_thr);
+    thr = reinterpret_cast<float*>(ws + o_thr);
     IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, cn, hint, thr, s), "hint threshold kernel");
   }
   hipEvent_t ev1 = nullptr;
-  rc = profile_open(ctx, s, &ev1);
-  if (rc) return rc;
+  if (!use_static) {   // timing events are created on demand, which allocates
+    rc = profile_open(ctx, s, &ev1);
+    if (rc) return rc;
+  }
   IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, plan, thr, part, s), "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   IC_HIP(ic::launch_rescore(xs, n, cs, part, plan, i1, d1, i2, d2, ratio, mask, rec, s),
          "rescore kernel");
-  return finish_call(ctx, s);
+  return use_static ? IC_OK : finish_call(ctx, s);
 }
 
 }  // namespace
@@ -233,6 +256,23 @@ int ic_create(int device, void** handle) {
   if (!guard.ok) { delete c; return fail_hip(guard.err, "hipSetDevice"); }
   e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
   if (e != hipSuccess) { delete c; return fail_hip(e, "hipEventCreate"); }
+  // per-device set-up, with `device` current: kernel attributes, and where this GPU keeps its
+  // copy of the static scratch array
+  e = ic::assign_init();
+  if (e == hipSuccess) e = ic::reduce_init();
+  if (e != hipSuccess) {
+    (void)hipEventDestroy(c->done);
+    delete c;
+    return fail_hip(e, "hipFuncSetAttribute");
+  }
+  void* sp = nullptr;
+  e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !sp) {
+    (void)hipEventDestroy(c->done);
+    delete c;
+    return fail_hip(e, "hipGetSymbolAddress(scratch)");
+  }
+  c->static_scratch = static_cast<char*>(sp);
   *handle = c;
   return IC_OK;
 }
@@ -307,6 +347,13 @@ int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int6
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1: idx is NULL");
   return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
                      nullptr, stream, "ic_assign_top1");
+}
+
+int ic_assign_top1_static(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                          const float* c_sqnorm, int32_t* idx, float* dist, void* stream) {
+  if (!idx) return fail(IC_EINVAL, "ic_assign_top1_static: idx is NULL");
+  return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
+                     nullptr, stream, "ic_assign_top1_static", nullptr, /*use_static=*/true);
 }
 
 int ic_assign_top1_hint(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,

@@ -386,6 +386,13 @@ __device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st
   }
 }
 
+// Slot of row r's record from K-split sp.  Split 0 of every row comes first ([N] records); only
+// the rows from split_row0 on (the last, partly filled round of row tiles) have further splits,
+// stored behind as [nsplit - 1][N - split_row0].
+__device__ __forceinline__ int64_t part_slot(int sp, int64_t r, int64_t N, int64_t split_row0) {
+  return sp == 0 ? r : N + (int64_t)(sp - 1) * (N - split_row0) + (r - split_row0);
+}
+
 template <int XT, int NW, int SK, int SKIP>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     if (h == 0 && r < N) {
       ic_top2_rec rec;
       rec.d1 = b.d1; rec.i1 = b.i1; rec.d2 = b.d2; rec.i2 = b.i2;
-      part[(int64_t)sp * N + r] = rec;
+      part[part_slot(sp, r, N, (int64_t)full_tiles * (XT * NW * 32))] = rec;
     }
   }
 }
@@ -530,17 +537,41 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   auto kern = variant == 0 ? k_top2_partial<kXT, NW, SK, 0>
               : variant == 1 ? k_top2_partial<kXT, NW, SK, 1>
               : variant == 3 ? k_top2_partial<kXT, NW, SK, 3> : k_top2_partial<kXT, NW, SK, 2>;
-  const int lds = 2 * Stage<SK>::kBytes;
-  // per device and cheap, so it is simply repeated on every call
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
+  const int lds = 2 * Stage<SK>::kBytes;   // allowed by assign_init() on this device
   const int64_t grid = plan.full_tiles + split_tiles * plan.nsplit;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, cn_pad,
                      (int)stages, plan.stages_per_split, (int)plan.full_tiles, (int)split_tiles,
                      thr, part);
   return hipGetLastError();
+}
+
+template <int NW, int SK>
+static hipError_t allow_lds() {
+  const int lds = 2 * Stage<SK>::kBytes;
+  const void* kerns[4] = {reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 0>),
+                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 1>),
+                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 2>),
+                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 3>)};
+  for (const void* kp : kerns) {
+    hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// Once per device (from ic_create, with that device current): the search kernels use more dynamic
+// LDS than a launch may ask for by default.  Nothing is configured at launch time.
+hipError_t assign_init() {
+  hipError_t e = allow_lds<8, 64>();
+  if (e != hipSuccess) return e;
+  return allow_lds<16, 128>();
+}
+
+int64_t assign_part_records(const AssignPlan& p, int64_t n) {
+  int64_t split_row0 = p.full_tiles * (int64_t)p.rows_per_wg;
+  if (split_row0 > n) split_row0 = n;
+  return n + (int64_t)(p.nsplit - 1) * (n - split_row0);
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
@@ -595,7 +626,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     ic_top2_rec b = part[row];
     const int ns = row >= split_row0 ? nsplit : 1;   // rows below split_row0 were not split
     for (int s = 1; s < ns; ++s) {
-      const ic_top2_rec o = part[(int64_t)s * N + row];
+      const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
       top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
     }
     const float* xrow = X + row * kD + sub * 8;

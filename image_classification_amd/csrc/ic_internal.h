@@ -19,20 +19,25 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 // Decomposition of one search.  Geometry: workgroups of `waves` waves hold rows_per_wg rows in
 // registers and stream the codebook through LDS in stages of stage_k codewords.  The first
 // full_tiles row tiles are scanned over the whole codebook by one workgroup each, the remaining
-// ones in nsplit K-splits of stages_per_split stages; the partial buffer holds nsplit * n records.
+// ones in nsplit K-splits of stages_per_split stages.
 struct AssignPlan {
   int waves, stage_k, rows_per_wg;
   int64_t row_tiles, full_tiles;
   int nsplit, stages_per_split;
 };
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p);
+// records the partial buffer of a plan holds: one per row, plus nsplit - 1 more for every row of
+// the K-split tail
+int64_t assign_part_records(const AssignPlan& p, int64_t n);
+// once per device, with that device current: function attributes of the search kernels
+hipError_t assign_init();
 
 hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s);
 // cn_pad[j] = |c_j|^2 for j < k (or a copy of c_sqnorm), +inf for k <= j < kpad.
 hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const float* c_sqnorm,
                                  float* cn_pad, hipStream_t s);
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
-// part [nsplit][n]: per K-split (cn - 2 x.c, index) best and second best.
+// part [assign_part_records]: per K-split (cn - 2 x.c, index) best and second best.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* cn_pad, const AssignPlan& plan, const float* thr,
                                ic_top2_rec* part, hipStream_t s);
@@ -54,6 +59,7 @@ hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t 
                              hipStream_t s);
 
 // ---- ic_reduce.hip ---------------------------------------------------------------------------
+hipError_t reduce_init();   // once per device: function attributes of the histogram kernel
 // cell_w (nullable): per-cell weights, bin b belongs to cell b / cell_k (raw counts only).
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
                        int norm_mode, double power, const double* cell_w, int64_t cell_k,

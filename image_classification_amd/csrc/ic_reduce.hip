@@ -169,6 +169,14 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_normalise(int64_t k, int 
   }
 }
 
+// Once per device (from ic_create, with that device current): the histogram kernel may use the
+// dynamic LDS of its widest bin range.
+hipError_t reduce_init() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist),
+                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (kHistMaxBins + (kHistThreads / 64) * kTagSlots) * 4);
+}
+
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
                        int norm_mode, double power, const double* cell_w, int64_t cell_k,
                        double* out, hipStream_t s) {
@@ -176,15 +184,11 @@ hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_i
   const int bins_per_wg = k < kHistMaxBins ? (int)k : kHistMaxBins;
   const int64_t n_ranges = (k + bins_per_wg - 1) / bins_per_wg;
   if (n_img > 0x7fffffffLL || n_ranges > 65535) return hipErrorInvalidValue;
-  const int lds = (bins_per_wg + (kHistThreads / 64) * kTagSlots) * 4;
-  // per device and cheap, so it is simply repeated on every call
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
+  const int lds = (bins_per_wg + (kHistThreads / 64) * kTagSlots) * 4;   // see reduce_init()
   const int fused = n_ranges == 1 ? 1 : 0;
   hipLaunchKernelGGL(k_hist, dim3((unsigned)n_img, (unsigned)n_ranges), dim3(kHistThreads), lds, s,
                      codes, offsets, k, bins_per_wg, norm_mode, power, fused, cell_w, cell_k, out);
-  e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (!fused && norm_mode != IC_NORM_NONE && !cell_w) {
     hipLaunchKernelGGL(k_hist_normalise, dim3((unsigned)n_img), dim3(kHistThreads), 0, s, k,

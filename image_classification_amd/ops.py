@@ -105,6 +105,20 @@ def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None, hint=None):
     return idx, dist
 
 
+def assign_top1_static(x, c, c_sqnorm, out):
+    """assign_top1 through the entry point that allocates nothing (static device scratch, launches
+    only).  `out` = (idx int32 [n], dist float32 [n] or None), preallocated by the caller.  Raises
+    when the input needs more scratch than the static buffer holds."""
+    _check_pair(x, c)
+    dev = _dev_index(x)
+    idx, dist = out
+    rc = _lib.load().ic_assign_top1_static(_lib.handle(dev), _ptr(x), x.shape[0], _ptr(c),
+                                           c.shape[0], x.shape[1], _ptr(c_sqnorm), _ptr(idx),
+                                           _ptr(dist), _stream_ptr(dev))
+    _lib.check(rc, "ic_assign_top1_static")
+    return idx, dist
+
+
 def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True, out=None):
     """Two nearest rows of c per row of x, ascending (distance, index), and the ratio-test mask.
     `out` = (i1, d1, i2, d2, mask) preallocated contiguous device tensors."""

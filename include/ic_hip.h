@@ -32,6 +32,11 @@ extern "C" {
 #define IC_EINVAL 10001   /* bad argument (null pointer, negative size, unsupported d, ...) */
 #define IC_ENOMEM 10002   /* workspace allocation failed */
 #define IC_EHANDLE 10003  /* null / destroyed handle */
+#define IC_ELIMIT 10004   /* input larger than the static scratch of ic_assign_top1_static */
+
+/* Size of the device scratch buffer ic_assign_top1_static works in (per GPU, held from the moment
+ * the library is loaded on that GPU until the process ends). */
+#define IC_STATIC_SCRATCH_BYTES (64u << 20)
 
 /* normalisation modes of ic_hist */
 #define IC_NORM_NONE 0     /* raw counts */
@@ -81,6 +86,20 @@ int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, vo
  *   idx [n] int32, dist [n] f32 or NULL. */
 int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                    const float* c_sqnorm, int32_t* idx, float* dist, void* stream);
+
+/* ic_assign_top1 for callers that cannot allocate.  It has no counterpart in the reference; it
+ * exists for code under HIP graph capture, tight serving loops and harnesses that forbid
+ * hipMalloc.  Same arguments and the same results as ic_assign_top1, but the partial results
+ * (padded norms, per-row records of the K-splits, zero-padded copies when d < 128) live in a
+ * static device array of IC_STATIC_SCRATCH_BYTES instead of the handle's growable workspace, and
+ * the call consists of kernel launches on `stream` only: no hipMalloc / hipFree, no event, no
+ * synchronisation.  Inputs that need more scratch are rejected with IC_ELIMIT before anything is
+ * launched (16 bytes per row, plus 16 more per K-split for the rows of the last partly filled
+ * round of workgroups, plus 4 bytes per codeword: 1M rows x 10k codewords fits, about 4M rows is
+ * the ceiling).  All calls on one GPU share that array -- from every handle and every stream --
+ * so two calls that overlap in time on one GPU race; order them on one stream or with events. */
+int ic_assign_top1_static(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
+                          const float* c_sqnorm, int32_t* idx, float* dist, void* stream);
 
 /* ic_assign_top1 with a guess of every row's nearest codeword (k-means: the labels of the
  * previous Lloyd iteration inside kmeans2, vision/facerec/face_indexing.py:158).  The result is
