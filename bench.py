@@ -563,6 +563,17 @@ def run_rank(args):
     kern_ms, launches = ops.profile_end(local_rank)
     (dt_max,) = fence.max_over_ranks([dt])
 
+    second_look = None
+    if args.workload != "histknn":
+        # outside the timed region: how many rows of one more step the search could not decide
+        # from its two candidates and searched again by direct differences
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.debug_flagged(local_rank, counter)
+        step()
+        torch.cuda.synchronize()
+        ops.debug_flagged(local_rank, None)
+        second_look = int(counter.item())
+
     phases = None
     if args.workload == "kmeans":
         phases, _c, _l = kmeans_phases(torch, fence, D, backend, x, state["c"], state["labels"],
@@ -622,6 +633,7 @@ def run_rank(args):
                        "codebook": k_words if not is_pairs else int(flops_per_launch / (2.0 * n_rows * DIM)),
                        "dim": k_words if is_hist else DIM,
                        "parallelism": parallelism,
+                       "rows_given_a_second_direct_look": second_look,
                        "ranks": world,
                        "rccl_ranks": dist.get_world_size() if use_dist and args.dist_backend == "nccl" else 0,
                        "dist_backend": args.dist_backend if use_dist else None},

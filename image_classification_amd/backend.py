@@ -47,13 +47,13 @@ class HipBackend(object):
         x_np = _as_f32_rows(x_np)
         if x_np.shape[0] <= ops.HOST_CHUNK_ROWS:
             return self.assign_top1(self.f32(x_np), cb, want_dist)
-        return ops.assign_from_host(x_np, cb.c, cb.sqnorm, top2=False, want_dist=want_dist)
+        return ops.assign_from_host(x_np, cb.c, cb.aux, top2=False, want_dist=want_dist)
 
     def assign_top2_np(self, x_np, cb, ratio=0.8):
         x_np = _as_f32_rows(x_np)
         if x_np.shape[0] <= ops.HOST_CHUNK_ROWS:
             return self.assign_top2(self.f32(x_np), cb, ratio)
-        return ops.assign_from_host(x_np, cb.c, cb.sqnorm, top2=True, ratio=ratio)
+        return ops.assign_from_host(x_np, cb.c, cb.aux, top2=True, ratio=ratio)
 
     # -- searches whose rows are a list of host arrays (one per image): threaded gather ---------
     def assign_top1_parts(self, parts, cb, want_dist=True):
@@ -61,24 +61,24 @@ class HipBackend(object):
         if total <= ops.HOST_CHUNK_ROWS // 4:
             x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
             return self.assign_top1(self.f32(x_np), cb, want_dist)
-        return ops.assign_from_host_parts(parts, cb.c, cb.sqnorm, top2=False, want_dist=want_dist)
+        return ops.assign_from_host_parts(parts, cb.c, cb.aux, top2=False, want_dist=want_dist)
 
     def assign_top2_parts(self, parts, cb, ratio=0.8):
         total = sum(p.shape[0] for p in parts)
         if total <= ops.HOST_CHUNK_ROWS // 4:
             x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
             return self.assign_top2(self.f32(x_np), cb, ratio)
-        return ops.assign_from_host_parts(parts, cb.c, cb.sqnorm, top2=True, ratio=ratio)
+        return ops.assign_from_host_parts(parts, cb.c, cb.aux, top2=True, ratio=ratio)
 
     # -- operators -----------------------------------------------------------------------------
     def assign_top1(self, x, cb, want_dist=True, hint=None):
-        return ops.assign_top1(x, cb.c, cb.sqnorm, want_dist, hint=hint)
+        return ops.assign_top1(x, cb.c, cb.aux, want_dist, hint=hint)
 
     def assign_top2(self, x, cb, ratio=0.8):
-        return ops.assign_top2(x, cb.c, ratio, cb.sqnorm)
+        return ops.assign_top2(x, cb.c, ratio, cb.aux)
 
     def assign_top2_rec(self, x, cb):
-        return ops.assign_top2_rec(x, cb.c, cb.sqnorm)
+        return ops.assign_top2_rec(x, cb.c, cb.aux)
 
     def top2_merge(self, gathered, shard_base, ratio=0.8):
         return ops.top2_merge(gathered, shard_base, ratio)

@@ -47,6 +47,7 @@ struct Ctx {
   char* ws = nullptr;
   size_t ws_bytes = 0;
   char* static_scratch = nullptr;  // this device's address of `scratch`
+  uint32_t* debug_count = nullptr; // device word that receives each search's flagged-row count
   hipEvent_t done = nullptr;      // recorded after each call's last launch
   hipStream_t last_stream = nullptr;
   bool have_last = false;
@@ -150,19 +151,28 @@ int profile_open(Ctx* c, hipStream_t s, hipEvent_t* stop) {
     if (e__ != hipSuccess) return fail_hip(e__, what); \
   } while (0)
 
-// Shared body of the three search entry points.
+// Shared body of the search entry points.
+//
+// Launch sequence: [pad rows and codebook to 128 columns] -> [auxiliary block of the codebook,
+// unless the caller brought one] -> [hint thresholds] -> matrix-core search (best, second best and
+// the value of the third per row and K-split) -> k_rescore (merge, direct evaluation of the pair,
+// outputs, flags) + list of flagged rows -> direct search of the flagged rows, overwriting their
+// outputs.  The number of flagged rows never reaches the host.
 int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                const float* c_aux, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
                 uint8_t* mask, ic_top2_rec* rec, void* stream, const char* who,
                 const int32_t* hint = nullptr, bool use_static = false) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "%s: invalid handle", who);
-  if (n < 0 || k < 1 || k > 0x7fffffffLL) return fail(IC_EINVAL, "%s: need n >= 0 and 1 <= k < 2^31 (n=%lld k=%lld)", who, (long long)n, (long long)k);
+  if (n < 0 || n >= 0x7fffffffLL || k < 1 || k > 0x7fffffffLL)
+    return fail(IC_EINVAL, "%s: need 0 <= n < 2^31 and 1 <= k < 2^31 (n=%lld k=%lld)", who,
+                (long long)n, (long long)k);
   if (d < 1 || d > ic::kD) return fail(IC_EINVAL, "%s: descriptor dimension %d not in [1,%d]", who, d, ic::kD);
   if (n == 0) return IC_OK;
   if (!x || !c) return fail(IC_EINVAL, "%s: x and c must not be NULL", who);
   if (!i1 && !rec) return fail(IC_EINVAL, "%s: no output buffer given", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool mode2 = i2 || d2 || mask || rec;   // the second neighbour is part of the answer
 
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
@@ -172,13 +182,22 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   ic::AssignPlan plan;
   ic::assign_plan(n, k, ctx->num_cus, &plan);
   const bool pad = d != ic::kD;
+  const size_t records = (size_t)ic::assign_part_records(plan, n);
+  const int64_t rs_grid = (n + ic::rescore_chunk(n) - 1) / ic::rescore_chunk(n);
   size_t off = 0;
-  const size_t o_cn = off;   off += align_up((size_t)kpad * 4);
-  const size_t o_part = off;
-  off += align_up((size_t)ic::assign_part_records(plan, n) * sizeof(ic_top2_rec));
-  const size_t o_xp = off;   if (pad) off += align_up((size_t)n * ic::kD * 4);
-  const size_t o_cp = off;   if (pad) off += align_up((size_t)k * ic::kD * 4);
-  const size_t o_thr = off;  if (hint) off += align_up((size_t)n * 4);
+  auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
+  const size_t o_aux = c_aux ? 0 : take((size_t)(ic::kAuxNorms + kpad) * 4);
+  const size_t o_auxs = c_aux ? 0 : take(ic::codebook_aux_scratch_bytes(k));
+  const size_t o_part = take(records * sizeof(ic_top2_rec));
+  const size_t o_part3 = take(records * 4);
+  const size_t o_flags = take((size_t)n);
+  const size_t o_cnt = take((size_t)rs_grid * 4);
+  const size_t o_list = take((size_t)n * 4);
+  const size_t o_count = take(4);
+  const size_t o_expart = take((size_t)ic::kExactGrid * 16 * sizeof(ic_top2_rec));
+  const size_t o_xp = pad ? take((size_t)n * ic::kD * 4) : 0;
+  const size_t o_cp = pad ? take((size_t)k * ic::kD * 4) : 0;
+  const size_t o_thr = hint ? take((size_t)n * 4) : 0;
   int rc;
   char* ws;
   if (use_static) {
@@ -196,8 +215,8 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     ws = ctx->ws;
   }
 
-  float* cn = reinterpret_cast<float*>(ws + o_cn);
   ic_top2_rec* part = reinterpret_cast<ic_top2_rec*>(ws + o_part);
+  float* part3 = reinterpret_cast<float*>(ws + o_part3);
   const float* xs = x;
   const float* cs = c;
   if (pad) {
@@ -208,21 +227,39 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     xs = xp;
     cs = cp;
   }
-  IC_HIP(ic::launch_codebook_norms(cs, k, kpad, c_sqnorm, cn, s), "codebook norms");
+  const float* aux = c_aux;
+  if (!aux) {
+    float* a = reinterpret_cast<float*>(ws + o_aux);
+    IC_HIP(ic::launch_codebook_aux(cs, k, a, ws + o_auxs, s), "codebook auxiliary block");
+    aux = a;
+  }
   float* thr = nullptr;
   if (hint) {
     thr = reinterpret_cast<float*>(ws + o_thr);
-    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, cn, hint, thr, s), "hint threshold kernel");
+    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, aux, hint, thr, s), "hint threshold kernel");
   }
   hipEvent_t ev1 = nullptr;
   if (!use_static) {   // timing events are created on demand, which allocates
     rc = profile_open(ctx, s, &ev1);
     if (rc) return rc;
   }
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, cn, plan, thr, part, s), "distance/top-2 kernel");
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, part, part3, s),
+         "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
-  IC_HIP(ic::launch_rescore(xs, n, cs, part, plan, i1, d1, i2, d2, ratio, mask, rec, s),
-         "rescore kernel");
+  int32_t* list = reinterpret_cast<int32_t*>(ws + o_list);
+  uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, part, part3, plan, mode2, i1, d1, i2, d2, ratio, mask,
+                            rec, reinterpret_cast<uint8_t*>(ws + o_flags),
+                            reinterpret_cast<uint32_t*>(ws + o_cnt), list, count, s),
+         "rescore kernels");
+  IC_HIP(ic::launch_exact_rows(xs, n, cs, k, list, count,
+                               reinterpret_cast<ic_top2_rec*>(ws + o_expart), i1, d1, i2, d2,
+                               ratio, mask, rec, s),
+         "direct search of the flagged rows");
+  if (ctx->debug_count) {   // ic_debug_flagged: how many rows took the second look
+    IC_HIP(hipMemcpyAsync(ctx->debug_count, count, 4, hipMemcpyDeviceToDevice, s),
+           "hipMemcpyAsync");
+  }
   return use_static ? IC_OK : finish_call(ctx, s);
 }
 
@@ -342,34 +379,73 @@ int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, vo
   return IC_OK;
 }
 
+int64_t ic_codebook_aux_floats(int64_t k) {
+  if (k < 1) return 0;
+  return ic::kAuxNorms + (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
+}
+
+int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, void* stream) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_codebook_aux: invalid handle");
+  if (k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kD)
+    return fail(IC_EINVAL, "ic_codebook_aux: bad shape k=%lld d=%d", (long long)k, d);
+  if (!c || !aux) return fail(IC_EINVAL, "ic_codebook_aux: NULL pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  const bool pad = d != ic::kD;
+  const size_t o_cp = align_up(ic::codebook_aux_scratch_bytes(k));
+  int rc = ensure_ws(ctx, o_cp + (pad ? align_up((size_t)k * ic::kD * 4) : 0));
+  if (rc) return rc;
+  rc = order_after_previous(ctx, s);
+  if (rc) return rc;
+  const float* cs = c;
+  if (pad) {
+    float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
+    IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
+    cs = cp;
+  }
+  IC_HIP(ic::launch_codebook_aux(cs, k, aux, ctx->ws, s), "codebook auxiliary block");
+  return finish_call(ctx, s);
+}
+
+int ic_debug_flagged(void* handle, uint32_t* count) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_debug_flagged: invalid handle");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->debug_count = count;
+  return IC_OK;
+}
+
 int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                   const float* c_sqnorm, int32_t* idx, float* dist, void* stream) {
+                   const float* c_aux, int32_t* idx, float* dist, void* stream) {
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1: idx is NULL");
-  return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
+  return assign_impl(handle, x, n, c, k, d, c_aux, idx, dist, nullptr, nullptr, 0.f, nullptr,
                      nullptr, stream, "ic_assign_top1");
 }
 
 int ic_assign_top1_static(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                          const float* c_sqnorm, int32_t* idx, float* dist, void* stream) {
+                          const float* c_aux, int32_t* idx, float* dist, void* stream) {
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1_static: idx is NULL");
-  return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
+  return assign_impl(handle, x, n, c, k, d, c_aux, idx, dist, nullptr, nullptr, 0.f, nullptr,
                      nullptr, stream, "ic_assign_top1_static", nullptr, /*use_static=*/true);
 }
 
 int ic_assign_top1_hint(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                        const float* c_sqnorm, const int32_t* hint, int32_t* idx, float* dist,
+                        const float* c_aux, const int32_t* hint, int32_t* idx, float* dist,
                         void* stream) {
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1_hint: idx is NULL");
   if (!hint && n > 0) return fail(IC_EINVAL, "ic_assign_top1_hint: hint is NULL");
-  return assign_impl(handle, x, n, c, k, d, c_sqnorm, idx, dist, nullptr, nullptr, 0.f, nullptr,
+  return assign_impl(handle, x, n, c, k, d, c_aux, idx, dist, nullptr, nullptr, 0.f, nullptr,
                      nullptr, stream, "ic_assign_top1_hint", hint);
 }
 
 int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                   const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2,
+                   const float* c_aux, int32_t* i1, float* d1, int32_t* i2, float* d2,
                    float ratio, uint8_t* mask, void* stream) {
   if (!i1) return fail(IC_EINVAL, "ic_assign_top2: i1 is NULL");
-  return assign_impl(handle, x, n, c, k, d, c_sqnorm, i1, d1, i2, d2, ratio, mask, nullptr, stream,
+  return assign_impl(handle, x, n, c, k, d, c_aux, i1, d1, i2, d2, ratio, mask, nullptr, stream,
                      "ic_assign_top2");
 }
 
@@ -407,9 +483,9 @@ int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c
 }
 
 int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                       const float* c_sqnorm, ic_top2_rec* rec, void* stream) {
+                       const float* c_aux, ic_top2_rec* rec, void* stream) {
   if (!rec) return fail(IC_EINVAL, "ic_assign_top2_rec: rec is NULL");
-  return assign_impl(handle, x, n, c, k, d, c_sqnorm, nullptr, nullptr, nullptr, nullptr, 0.f,
+  return assign_impl(handle, x, n, c, k, d, c_aux, nullptr, nullptr, nullptr, nullptr, 0.f,
                      nullptr, rec, stream, "ic_assign_top2_rec");
 }
 

@@ -26,6 +26,17 @@
 //     workgroup writes one (value, index) x 2 record per row, k_rescore merges the splits.
 //   * ranking is gated twice (tile minimum, then per register) because on gfx950 the fp32 MFMA
 //     and the vector ALU never co-execute: every ranking instruction costs MFMA time.
+//
+// Exactness.  The values the matrix cores rank by, |c - m|^2 - 2 (x - m).c (m = the codebook's
+// mean vector: distances do not change under a common shift, the magnitudes that drive the
+// rounding error do), carry an absolute error of up to `B` (see error_bound).  Besides the two
+// best candidates every lane therefore tracks the VALUE of the third best, and ranks every
+// candidate that comes within the error band of the best (top-1 searches) or of the second best
+// (top-2 searches).  k_rescore then knows, per row, whether any candidate outside the pair it holds
+// could be the true nearest (or second nearest): if not, evaluating the pair with direct
+// differences decides the row; if so the row is flagged and searched again by direct differences
+// over the whole codebook (k_exact_rows).  The direct-difference arithmetic is the same function in
+// both places, so results equal those of the all-direct search (ic_assign_top2_exact) on every row.
 #include <cstdlib>
 
 #include "ic_internal.h"
@@ -171,18 +182,28 @@ __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
 }
 
 struct Top2 {
-  float d1, d2;
+  float d1, d2, d3;   // best, second best, and the VALUE of the third best
   int i1, i2;
 };
 
-struct FinalOutExact {   // outputs of k_exact_top2 (any pointer may be null)
-  int32_t* i1;
-  float* d1;
-  int32_t* i2;
-  float* d2;
-  float ratio;
-  uint8_t* mask;
-};
+// Rounding model.  The MFMA chain is a k-ordered float32 fma chain: starting from cn = |c - m|^2
+// it adds the 128 products -2 (x - m)_i c_i, one rounding each, every partial sum bounded by
+// cn + 2 |x - m| |c|.  With u = 2^-24, and 16 u cn for the rounding of cn itself and 2 u |x-m||c|
+// for that of x - m, the computed value differs from the exact one by at most
+//     u (144 cn + 258 |x - m| |c|)  <=  B := u (150 Cn + 270 |x - m| Cr),
+// Cn = max_j |c_j - m|^2, Cr = max_j |c_j|.
+constexpr float kU = 5.9604645e-8f;            // 2^-24
+constexpr float kGammaDirect = 129.f * kU;      // relative error bound of a 128-term sum (x-c)^2
+__device__ __forceinline__ float error_bound(float xn_centred, float cn_max, float cr2_max) {
+  return kU * (150.f * cn_max + 270.f * __builtin_sqrtf(xn_centred * cr2_max));
+}
+// Band below which another candidate may really be nearer than the reference candidate with
+// computed value v: two error bounds, plus the room the direct float32 evaluation of the two
+// squared distances (about R + v each, R = |x-m|^2 + 2 (x-m).m) needs to order them.
+// In the search kernel: band(v) = c0 + kBandSlope * v with c0 = 2.01 B + kBandSlope * R.
+constexpr float kBandSlope = 4.f * kGammaDirect;
+// k_rescore decides with 2 B + 3 gamma s (s = the direct squared distance), which is never more.
+constexpr float kFlagSlope = 3.f * kGammaDirect;
 
 // Strict '<' and ascending visiting order keep the lowest index on ties, as scipy's _vq.vq scan
 // and numpy's argmin do.
@@ -198,6 +219,21 @@ __device__ __forceinline__ void top2_update(float& d1r, float& d2r, int& i1r, in
   i1r = lt1 ? enc : i1;
   d2r = __builtin_amdgcn_fmed3f(v, d1, d2);
   d1r = lt1 ? v : d1;
+}
+
+// The same, also keeping the third smallest value seen (d1 <= d2 <= d3 on entry and on exit).
+__device__ __forceinline__ void top3_update(float& d1r, float& d2r, float& d3r, int& i1r, int& i2r,
+                                            float v, int enc) {
+  d3r = __builtin_amdgcn_fmed3f(v, d2r, d3r);
+  top2_update(d1r, d2r, i1r, i2r, v, enc);
+}
+
+// Third smallest of the union of two ascending triples.
+__device__ __forceinline__ float third_of_union(float a1, float a2, float a3, float e1, float e2,
+                                                float e3) {
+  // third smallest of the four values a1 <= a2, e1 <= e2, then the thirds themselves
+  const float t4 = __builtin_fminf(__builtin_fmaxf(a2, e1), __builtin_fmaxf(a1, e2));
+  return __builtin_fminf(t4, __builtin_fminf(a3, e3));
 }
 
 __device__ __forceinline__ bool lex_less(float da, int ia, float db, int ib) {
@@ -271,39 +307,20 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 // instructions hand-placed between the MFMAs of a chain did not hide behind them (measured: the
 // interleaved schedule was 6 % slower than ranking after the chain, and the same loop without any
 // ranking reaches 94.8 % of the MFMA peak against 83 % with it).  So ranking is made cheaper by
-// doing less of it: the minimum of the tile's 16 values (8 v_min3) is compared with the running
-// second best, and when no lane of the wave can improve its top-2 the update is skipped.
-template <int XT>
-__device__ __forceinline__ void tile_epilogue_skip(const f32x16 (&acc)[XT], Top2 (&st)[XT],
-                                                   int encbase) {
-#pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    const f32x16& a = acc[xt];
-    const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
-                          min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
-                          __builtin_inff());
-    if (__builtin_amdgcn_ballot_w64(m < st[xt].d2) != 0) {
-      // rank inside the tile with the register number (an inline constant) as index; -1 / -2
-      // stand for "the previous best / second best", resolved once after the 16 updates
-      float d1 = st[xt].d1, d2 = st[xt].d2;
-      int l1 = -1, l2 = -2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) top2_update(d1, d2, l1, l2, a[r], r);
-      const int o1 = st[xt].i1, o2 = st[xt].i2;
-      st[xt].d1 = d1;
-      st[xt].d2 = d2;
-      st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
-      st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
-    }
-  }
-}
-
-// The same, one level finer: inside a tile that some lane can improve, a register's candidate is
-// ranked only when some lane's value in THAT register beats its running second best (16 compares
-// and wave-uniform branches instead of 16 seven-instruction updates; a lane improves on about
-// 2/t of the tiles, so past the first few tiles most registers are skipped).
-template <int XT>
-__device__ __forceinline__ void tile_epilogue_skip2(const f32x16 (&acc)[XT], Top2 (&st)[XT],
+// doing less of it, in two levels: the minimum of the tile's 16 values (8 v_min3) is compared with
+// the lane's gate, and when no lane of the wave passes, the tile is skipped; inside a tile that
+// some lane can improve, a register's candidate is ranked only when some lane's value in THAT
+// register passes (16 compares and wave-uniform branches instead of 16 updates).
+//
+// The gate of a lane is the larger of its running second best and `ref + band(ref)`, ref = the
+// running best (MODE2 false: the caller wants the nearest codeword) or the running second best
+// (MODE2 true: the caller wants both).  Everything below the gate is ranked, so at the end d3 is
+// the third smallest value among all candidates that matter: a candidate that was never ranked
+// lay, when it was seen, above ref + band(ref) of that moment, and both only shrink afterwards.
+// Within a tile the gate of the tile's start is used (stale = larger = ranks a little more).
+template <int XT, bool MODE2>
+__device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top2 (&st)[XT],
+                                                    float (&gate)[XT], const float (&c0)[XT],
                                                     int encbase) {
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
@@ -311,78 +328,36 @@ __device__ __forceinline__ void tile_epilogue_skip2(const f32x16 (&acc)[XT], Top
     const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
                           min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
                           __builtin_inff());
-    if (__builtin_amdgcn_ballot_w64(m < st[xt].d2) != 0) {
-      float d1 = st[xt].d1, d2 = st[xt].d2;
-      int l1 = -1, l2 = -2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < d2) != 0, 0))
-          top2_update(d1, d2, l1, l2, a[r], r);
-      const int o1 = st[xt].i1, o2 = st[xt].i2;
-      st[xt].d1 = d1;
-      st[xt].d2 = d2;
-      st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
-      st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
-    }
-  }
-}
-
-// The same with a tighter gate.  The two lanes that hold one descriptor (lane and lane + 32) rank
-// different halves of every tile's codewords, and each lane's own second best is a loose bound for
-// the descriptor: once per stage the pair exchanges its lists, and a candidate is ranked only when
-// it is below min(own second best, second best of the pair's four entries).  The pair's value is
-// raised by two units in the last place first, so a candidate that ties it is still ranked and the
-// final merge by (value, index) sees it.  About half as many candidates get past the gate.
-template <int XT>
-__device__ __forceinline__ void tile_epilogue_skip3(const f32x16 (&acc)[XT], Top2 (&st)[XT],
-                                                    float (&gate)[XT], int encbase) {
-#pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    const f32x16& a = acc[xt];
-    const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
-                          min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
-                          __builtin_inff());
     if (__builtin_amdgcn_ballot_w64(m < gate[xt]) != 0) {
-      float d1 = st[xt].d1, d2 = st[xt].d2, g = gate[xt];
+      // rank inside the tile with the register number (an inline constant) as index; -1 / -2
+      // stand for "the previous best / second best", resolved once after the 16 updates
+      float d1 = st[xt].d1, d2 = st[xt].d2, d3 = st[xt].d3;
+      const float g = gate[xt];
       int l1 = -1, l2 = -2;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
-          // a lane whose value is below its own second best but not below its gate ranks it too:
-          // needless, never wrong
-          top2_update(d1, d2, l1, l2, a[r], r);
-          g = __builtin_fminf(g, d2);
-        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0))
+          top3_update(d1, d2, d3, l1, l2, a[r], r);   // lanes that did not pass: needless, never wrong
       const int o1 = st[xt].i1, o2 = st[xt].i2;
       st[xt].d1 = d1;
       st[xt].d2 = d2;
+      st[xt].d3 = d3;
       st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
       st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
-      gate[xt] = g;
+      gate[xt] = __builtin_fmaxf(d2, __builtin_fmaf(MODE2 ? d2 : d1, 1.f + kBandSlope, c0[xt]));
     }
   }
 }
 
+// Every candidate ranked (IC_AMD_VARIANT=0: the timing baseline of the gate).
 template <int XT>
-__device__ __forceinline__ void sync_gate(const Top2 (&st)[XT], float (&gate)[XT]) {
-#pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    const float od1 = __shfl_xor(st[xt].d1, 32);
-    const float od2 = __shfl_xor(st[xt].d2, 32);
-    // second smallest of {d1, d2, od1, od2} given d1 <= d2 and od1 <= od2
-    float s2 = __builtin_fminf(__builtin_fmaxf(st[xt].d1, od1), __builtin_fminf(st[xt].d2, od2));
-    s2 = __builtin_fmaf(__builtin_fmaxf(__builtin_fabsf(s2), 1e-30f), 0x1p-22f, s2);
-    gate[xt] = __builtin_fminf(st[xt].d2, s2);
-  }
-}
-
-template <int XT>
-__device__ __forceinline__ void tile_epilogue(const f32x16 (&acc)[XT], Top2 (&st)[XT], int encbase) {
+__device__ __forceinline__ void tile_epilogue_all(const f32x16 (&acc)[XT], Top2 (&st)[XT],
+                                                  int encbase) {
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      top2_update(st[xt].d1, st[xt].d2, st[xt].i1, st[xt].i2, acc[xt][r], encbase + r);
+      top3_update(st[xt].d1, st[xt].d2, st[xt].d3, st[xt].i1, st[xt].i2, acc[xt][r], encbase + r);
   }
 }
 
@@ -393,16 +368,20 @@ __device__ __forceinline__ int64_t part_slot(int sp, int64_t r, int64_t N, int64
   return sp == 0 ? r : N + (int64_t)(sp - 1) * (N - split_row0) + (r - split_row0);
 }
 
-template <int XT, int NW, int SK, int SKIP>
+// aux: the codebook's auxiliary block (see AuxLayout in ic_internal.h): mean vector, the two
+// maxima of the rounding model, then the centred squared norms (+inf in the padding).
+template <int XT, int NW, int SK, bool GATED, bool MODE2>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
-    const float* __restrict__ cnp, int stages_total, int stages_per_split, int full_tiles,
-    int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part) {
+    const float* __restrict__ aux, int stages_total, int stages_per_split, int full_tiles,
+    int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
+    float* __restrict__ part3) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31;  // descriptor (B column / result column) and codeword row (A row)
   const int h = lane >> 5;  // which half of the 128 components this lane multiplies
+  const float* __restrict__ cnp = aux + kAuxNorms;
 
   // the first full_tiles workgroups scan the whole codebook; the rest are (row tile, K-split) pairs
   int rt = blockIdx.x, sp = 0, st0 = 0, st1 = stages_total;
@@ -415,8 +394,8 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     st1 = st1 < stages_total ? st1 : stages_total;
   }
 
-  // descriptors of this wave, scaled by -2 (exact), 64 components per lane.  Their loads go out
-  // first, then the first two stages of the codebook.
+  // descriptors of this wave, 64 components per lane.  Their loads go out first, then the first
+  // two stages of the codebook.
   const int64_t row0 = (int64_t)rt * (XT * NW * 32) + (int64_t)wave * (XT * 32);
   f32x4 xv[XT][16];
 #pragma unroll
@@ -430,15 +409,31 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   issue_stage<NW, SK>(C, K, cnp, st0, smem, wave, lane);
   const bool two = st0 + 1 < st1;
   if (two) issue_stage<NW, SK>(C, K, cnp, st0 + 1, smem + Stage<SK>::kBytes, wave, lane);
+
+  // centre the rows on the codebook mean and scale by -2 (exact); on the way, this lane's half of
+  // |x - m|^2 and of (x - m).m for the band
   float xr[XT][64];
+  float c0[XT];
+  {
+    const f32x4* mp = reinterpret_cast<const f32x4*>(aux + h * 4);
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
+    for (int xt = 0; xt < XT; ++xt) {
+      float xn = 0.f, xm = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      xr[xt][q * 4 + 0] = -2.0f * xv[xt][q][0];
-      xr[xt][q * 4 + 1] = -2.0f * xv[xt][q][1];
-      xr[xt][q * 4 + 2] = -2.0f * xv[xt][q][2];
-      xr[xt][q * 4 + 3] = -2.0f * xv[xt][q][3];
+      for (int q = 0; q < 16; ++q) {
+        const f32x4 mu = mp[2 * q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = xv[xt][q][e] - mu[e];
+          xn = __builtin_fmaf(t, t, xn);
+          xm = __builtin_fmaf(t, mu[e], xm);
+          xr[xt][q * 4 + e] = -2.0f * t;
+        }
+      }
+      xn += __shfl_xor(xn, 32);
+      xm += __shfl_xor(xm, 32);
+      const float bound = error_bound(xn, aux[kAuxCnMax], aux[kAuxCr2Max]);
+      c0[xt] = 2.01f * bound + kBandSlope * (xn + 2.f * xm);
     }
   }
 
@@ -446,7 +441,8 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   float gate[XT];
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
-    // with a caller-supplied bound only candidates below it are ranked at all (index -1 = none)
+    // with a caller-supplied bound only candidates below it are ranked at all (index -1 = none);
+    // the bound then stands for every candidate that was never looked at
     float start = __builtin_inff();
     if (thr) {
       int64_t r = row0 + xt * 32 + j;
@@ -454,6 +450,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     }
     best[xt].d1 = start;
     best[xt].d2 = start;
+    best[xt].d3 = start;
     best[xt].i1 = -1;
     best[xt].i2 = -1;
     gate[xt] = start;
@@ -482,14 +479,11 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (st + 2 < st1) issue_stage<NW, SK>(C, K, cnp, st + 2, sb, wave, lane);
-        if constexpr (SKIP == 3) sync_gate<XT>(best, gate);
       }
       if (live) {
         const int encbase = (st * Stage<SK>::kTiles + t) * 16;
-        if constexpr (SKIP == 3) tile_epilogue_skip3<XT>(acc, best, gate, encbase);
-        else if constexpr (SKIP == 2) tile_epilogue_skip2<XT>(acc, best, encbase);
-        else if constexpr (SKIP == 1) tile_epilogue_skip<XT>(acc, best, encbase);
-        else tile_epilogue<XT>(acc, best, encbase);
+        if constexpr (GATED) tile_epilogue_gated<XT, MODE2>(acc, best, gate, c0, encbase);
+        else tile_epilogue_all<XT>(acc, best, encbase);
       }
     }
   }
@@ -507,52 +501,57 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     b.i2 = decode(b.i2);
     const float od1 = __shfl_xor(b.d1, 32);
     const float od2 = __shfl_xor(b.d2, 32);
+    const float od3 = __shfl_xor(b.d3, 32);
     const int oi1 = __shfl_xor(b.i1, 32);
     const int oi2 = __shfl_xor(b.i2, 32);
+    const float t3 = third_of_union(b.d1, b.d2, b.d3, od1, od2, od3);
     top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, od1, oi1, od2, oi2);
     const int64_t r = row0 + xt * 32 + j;
     if (h == 0 && r < N) {
       ic_top2_rec rec;
       rec.d1 = b.d1; rec.i1 = b.i1; rec.d2 = b.d2; rec.i2 = b.i2;
-      part[part_slot(sp, r, N, (int64_t)full_tiles * (XT * NW * 32))] = rec;
+      const int64_t slot = part_slot(sp, r, N, (int64_t)full_tiles * (XT * NW * 32));
+      part[slot] = rec;
+      part3[slot] = t3;
     }
   }
 }
 
-template <int NW, int SK>
-static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
-                                  const float* cn_pad, const AssignPlan& plan, const float* thr,
-                                  ic_top2_rec* part, hipStream_t s) {
-  const int64_t stages = (k + SK - 1) / SK;
-  const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
-  // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
-  // candidate, 1 = skip tiles no lane can improve, 2 (default) = also skip registers, 3 = the
-  // same against the bound the two lanes of a descriptor share (fewer ranked candidates, but with
-  // four waves per SIMD the exchange costs what it saves: 89.9 vs 89.8 % at 10 000 codewords,
-  // 84.3 vs 85.3 % at 1000)
+// IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
+// candidate, anything else (default) = the two-level gate.
+static bool gated_variant() {
   static const int variant = [] {
     const char* v = getenv("IC_AMD_VARIANT");
     return v ? atoi(v) : 2;
   }();
-  auto kern = variant == 0 ? k_top2_partial<kXT, NW, SK, 0>
-              : variant == 1 ? k_top2_partial<kXT, NW, SK, 1>
-              : variant == 3 ? k_top2_partial<kXT, NW, SK, 3> : k_top2_partial<kXT, NW, SK, 2>;
+  return variant != 0;
+}
+
+template <int NW, int SK>
+static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
+                                  const float* aux, const AssignPlan& plan, bool mode2,
+                                  const float* thr, ic_top2_rec* part, float* part3,
+                                  hipStream_t s) {
+  const int64_t stages = (k + SK - 1) / SK;
+  const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
+  auto kern = !gated_variant() ? k_top2_partial<kXT, NW, SK, false, false>
+              : mode2 ? k_top2_partial<kXT, NW, SK, true, true>
+                      : k_top2_partial<kXT, NW, SK, true, false>;
   const int lds = 2 * Stage<SK>::kBytes;   // allowed by assign_init() on this device
   const int64_t grid = plan.full_tiles + split_tiles * plan.nsplit;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, cn_pad,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
                      (int)stages, plan.stages_per_split, (int)plan.full_tiles, (int)split_tiles,
-                     thr, part);
+                     thr, part, part3);
   return hipGetLastError();
 }
 
 template <int NW, int SK>
 static hipError_t allow_lds() {
   const int lds = 2 * Stage<SK>::kBytes;
-  const void* kerns[4] = {reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 0>),
-                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 1>),
-                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 2>),
-                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, 3>)};
+  const void* kerns[3] = {reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, false, false>),
+                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, true, false>),
+                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, true, true>)};
   for (const void* kp : kerns) {
     hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
@@ -575,12 +574,12 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n) {
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, const AssignPlan& plan, const float* thr,
-                               ic_top2_rec* part, hipStream_t s) {
+                               const float* aux, const AssignPlan& plan, bool mode2,
+                               const float* thr, ic_top2_rec* part, float* part3, hipStream_t s) {
   if (plan.waves == 8 && plan.stage_k == 64)
-    return launch_geometry<8, 64>(x, n, c, k, cn_pad, plan, thr, part, s);
+    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, s);
   if (plan.waves == 16 && plan.stage_k == 128)
-    return launch_geometry<16, 128>(x, n, c, k, cn_pad, plan, thr, part, s);
+    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, s);
   return hipErrorInvalidValue;
 }
 
@@ -595,9 +594,17 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float sqdiff8(const f32x4& x0, const f32x4& x1, const float* crow) {
-  const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow);
-  const f32x4 c1 = *reinterpret_cast<const f32x4*>(crow + 4);
+// The direct squared distance sum (x - c)^2 in float32, in ONE summation order shared by
+// k_rescore (16 lanes per pair) and k_exact_top2 (one thread per codeword):
+//   p_s  = fma chain over components 8 s .. 8 s + 7, from 0            (s = 0 .. 15)
+//   b_q  = (p_4q + p_4q+1) + (p_4q+2 + p_4q+3)                         (q = 0 .. 3)
+//   sum  = ((b_0 + b_1) + b_2) + b_3
+// Float addition commutes bit for bit, so two xor-butterfly steps (partners 1, 2) leave b_q in
+// all four lanes of quad q, whatever the lane.  Both kernels returning identical bits for
+// identical pairs is what makes the fast path agree with the all-direct search on every row, not
+// only on most.
+__device__ __forceinline__ float chain8(const f32x4& x0, const f32x4& x1, const f32x4& c0,
+                                        const f32x4& c1) {
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -612,191 +619,415 @@ __device__ __forceinline__ float sqdiff8(const f32x4& x0, const f32x4& x1, const
   return s;
 }
 
+__device__ __forceinline__ float group16_tree(float p) {
+  p += __shfl_xor(p, 1, 16);
+  p += __shfl_xor(p, 2, 16);
+  const float b0 = __shfl(p, 0, 16), b1 = __shfl(p, 4, 16);
+  const float b2 = __shfl(p, 8, 16), b3 = __shfl(p, 12, 16);
+  return ((b0 + b1) + b2) + b3;
+}
+
+// 32 components of one (row, codeword) pair: xs points at the row's components in LDS, cv holds
+// the codeword's (8 float4).
+__device__ __forceinline__ float block32(const float* xs, const f32x4 (&cv)[8]) {
+  const f32x4* xv = reinterpret_cast<const f32x4*>(xs);
+  const float p0 = chain8(xv[0], xv[1], cv[0], cv[1]);
+  const float p1 = chain8(xv[2], xv[3], cv[2], cv[3]);
+  const float p2 = chain8(xv[4], xv[5], cv[4], cv[5]);
+  const float p3 = chain8(xv[6], xv[7], cv[6], cv[7]);
+  return (p0 + p1) + (p2 + p3);
+}
+
+struct FinalOut {   // outputs of a search (any pointer may be null)
+  int32_t* i1;
+  float* d1;
+  int32_t* i2;
+  float* d2;
+  float ratio;
+  uint8_t* mask;
+  ic_top2_rec* rec;
+};
+
+// s1 <= s2 by (value, index): squared distances in, Euclidean distances and the ratio test out.
+__device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, float s1, int a1,
+                                            float s2, int a2) {
+  const float e1 = __builtin_sqrtf(s1), e2 = __builtin_sqrtf(s2);
+  if (o.i1) o.i1[row] = a1;
+  if (o.d1) o.d1[row] = e1;
+  if (o.i2) o.i2[row] = a2;
+  if (o.d2) o.d2[row] = e2;
+  if (o.mask) o.mask[row] = (e1 < e2 * o.ratio) ? 1 : 0;
+  if (o.rec) {
+    ic_top2_rec r;
+    r.d1 = e1; r.i1 = a1; r.d2 = e2; r.i2 = a2;
+    o.rec[row] = r;
+  }
+}
+
+// Workgroup b owns rows [b chunk, (b + 1) chunk): merges their K-splits, evaluates the two
+// candidates of every row by direct differences, writes the outputs, and decides per row whether
+// the pair is certain to hold the answer (flags[row] = 0) or the row must be searched again by
+// direct differences (1); cnt[b] = number of its flagged rows.
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
-                                                 const ic_top2_rec* __restrict__ part, int nsplit,
-                                                 int64_t split_row0,
-                                                 int32_t* __restrict__ i1o, float* __restrict__ d1o,
-                                                 int32_t* __restrict__ i2o, float* __restrict__ d2o,
-                                                 float ratio, uint8_t* __restrict__ mask,
-                                                 ic_top2_rec* __restrict__ reco) {
+                                                 const float* __restrict__ aux,
+                                                 const ic_top2_rec* __restrict__ part,
+                                                 const float* __restrict__ part3, int nsplit,
+                                                 int64_t split_row0, int mode2, int64_t chunk,
+                                                 FinalOut out, uint8_t* __restrict__ flags,
+                                                 uint32_t* __restrict__ cnt) {
+  __shared__ int wcnt[16];
   const int sub = threadIdx.x & 15;
-  const int64_t stride = (int64_t)gridDim.x * 16;
-  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
+  const int grp = threadIdx.x >> 4;
+  const int64_t row_begin = (int64_t)blockIdx.x * chunk;
+  const int64_t row_end = row_begin + chunk < N ? row_begin + chunk : N;
+  const f32x4 m0 = *reinterpret_cast<const f32x4*>(aux + sub * 8);
+  const f32x4 m1 = *reinterpret_cast<const f32x4*>(aux + sub * 8 + 4);
+  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  int nflag = 0;
+  for (int64_t row = row_begin + grp; row < row_end; row += 16) {
     ic_top2_rec b = part[row];
+    float v3 = part3[row];
     const int ns = row >= split_row0 ? nsplit : 1;   // rows below split_row0 were not split
+    // v3: third smallest value over all splits; u3: the smallest "third of one split", i.e. the
+    // best candidate whose INDEX no record holds
+    float u3 = v3;
     for (int s = 1; s < ns; ++s) {
-      const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
+      const int64_t slot = part_slot(s, row, N, split_row0);
+      const ic_top2_rec o = part[slot];
+      const float o3 = part3[slot];
+      u3 = __builtin_fminf(u3, o3);
+      v3 = third_of_union(b.d1, b.d2, v3, o.d1, o.d2, o3);
       top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
     }
     const float* xrow = X + row * kD + sub * 8;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + 4);
+    const float xn = group16_sum(chain8(x0, x1, m0, m1));
+    auto direct = [&](int idx) {
+      const float* cr = C + (int64_t)idx * kD + sub * 8;
+      return group16_tree(chain8(x0, x1, *reinterpret_cast<const f32x4*>(cr),
+                                 *reinterpret_cast<const f32x4*>(cr + 4)));
+    };
     float s1 = __builtin_inff(), s2 = __builtin_inff();
-    if (b.i1 >= 0) s1 = group16_sum(sqdiff8(x0, x1, C + (int64_t)b.i1 * kD + sub * 8));
-    if (b.i2 >= 0) s2 = group16_sum(sqdiff8(x0, x1, C + (int64_t)b.i2 * kD + sub * 8));
+    if (b.i1 >= 0) s1 = direct(b.i1);
+    if (b.i2 >= 0) s2 = direct(b.i2);
+    // Can a candidate outside the pair be the nearest (the second nearest, when both count)?
+    // Only one whose computed value lies within `band` of the reference value: two error bounds,
+    // plus what the direct evaluation needs to tell it from the reference candidate(s) -- whose
+    // direct squared distance is s1 (the computed best) or, when both count, the larger of the two.
+    const float ref = mode2 ? b.d2 : b.d1;
+    const float band = 2.f * error_bound(xn, cn_max, cr2_max) +
+                       kFlagSlope * (mode2 ? __builtin_fmaxf(s1, s2) : s1);
     int a1 = b.i1, a2 = b.i2;
     if (a2 >= 0 && lex_less(s2, a2, s1, a1)) {
       const float ts = s1; s1 = s2; s2 = ts;
       const int ti = a1; a1 = a2; a2 = ti;
     }
-    const float e1 = __builtin_sqrtf(s1), e2 = __builtin_sqrtf(s2);
-    if (sub == 0) {
-      if (i1o) i1o[row] = a1;
-      if (d1o) d1o[row] = e1;
-      if (i2o) i2o[row] = a2;
-      if (d2o) d2o[row] = e2;
-      if (mask) mask[row] = (e1 < e2 * ratio) ? 1 : 0;
-      if (reco) {
-        ic_top2_rec r;
-        r.d1 = e1; r.i1 = a1; r.d2 = e2; r.i2 = a2;
-        reco[row] = r;
+    bool unsure = (v3 - ref) <= band;   // false on NaN / inf - inf
+    if (unsure && ns > 1 && !((u3 - ref) <= band)) {
+      // every candidate inside the band sits in the record of some split, index and all (no
+      // split has a third one there): evaluate them directly too and keep the two best of
+      // everything evaluated
+      for (int s = 0; s < ns; ++s) {
+        const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
+        const int cand[2] = {o.i1, o.i2};
+        const float val[2] = {o.d1, o.d2};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int idx = cand[t];
+          if (idx < 0 || idx == a1 || idx == a2 || !((val[t] - ref) <= band)) continue;
+          const float sd = direct(idx);
+          if (lex_less(sd, idx, s1, a1)) {
+            s2 = s1; a2 = a1; s1 = sd; a1 = idx;
+          } else if (a2 < 0 || lex_less(sd, idx, s2, a2)) {
+            s2 = sd; a2 = idx;
+          }
+        }
       }
+      unsure = false;
     }
+    if (sub == 0) {
+      write_final(out, row, s1, a1, s2, a2);
+      flags[row] = unsure ? 1 : 0;
+      nflag += unsure ? 1 : 0;
+    }
+  }
+  if (sub == 0) wcnt[grp] = nflag;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int g = 0; g < 16; ++g) t += wcnt[g];
+    cnt[blockIdx.x] = (uint32_t)t;
   }
 }
 
-hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
-                          const AssignPlan& plan, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                          uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
-  int64_t grid = (n + 15) / 16;
-  if (grid > 16384) grid = 16384;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, part, plan.nsplit,
-                     plan.full_tiles * (int64_t)plan.rows_per_wg, i1, d1, i2, d2, ratio, mask, rec);
+// Flags -> ascending list of flagged rows.  Workgroup b takes `cpw` consecutive chunks of
+// k_rescore's decomposition and places their rows behind those of all chunks before them; the
+// last workgroup also stores the total.
+__global__ __launch_bounds__(256) void k_flag_scatter(const uint8_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ cnt, int64_t N,
+                                                      int64_t chunk, int cpw,
+                                                      int32_t* __restrict__ list,
+                                                      uint32_t* __restrict__ count) {
+  __shared__ uint32_t red[4];
+  __shared__ uint32_t wave_n[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t before = 0;
+  const unsigned first_chunk = blockIdx.x * (unsigned)cpw;
+  for (unsigned i = threadIdx.x; i < first_chunk; i += 256) before += cnt[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off);
+  if (lane == 0) red[wave] = before;
+  __syncthreads();
+  uint32_t pos = red[0] + red[1] + red[2] + red[3];
+  const int64_t row_begin = (int64_t)first_chunk * chunk;
+  const int64_t row_end = row_begin + chunk * cpw < N ? row_begin + chunk * cpw : N;
+  for (int64_t base = row_begin; base < row_end; base += 256) {   // uniform trip count
+    const int64_t row = base + threadIdx.x;
+    const bool f = row < row_end && flags[row] != 0;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+    __syncthreads();   // wave_n of the previous round has been read
+    if (lane == 0) wave_n[wave] = (uint32_t)__builtin_popcountll(bal);
+    __syncthreads();
+    uint32_t wbase = pos;
+    for (int w = 0; w < wave; ++w) wbase += wave_n[w];
+    if (f) list[wbase + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int32_t)row;
+    pos += wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count = pos;
+}
+
+// Rows per workgroup of k_rescore: few, so that many independent gathers are in flight, but never
+// more than 16384 workgroups (their counts are summed by every workgroup of k_flag_scatter).
+int64_t rescore_chunk(int64_t n) {
+  int64_t chunk = (n + 16383) / 16384;
+  chunk = (chunk + 15) / 16 * 16;
+  return chunk < 64 ? 64 : chunk;
+}
+
+hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
+                          const ic_top2_rec* part, const float* part3, const AssignPlan& plan,
+                          bool mode2, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          uint8_t* mask, ic_top2_rec* rec, uint8_t* flags, uint32_t* cnt,
+                          int32_t* list, uint32_t* count, hipStream_t s) {
+  const int64_t chunk = rescore_chunk(n);
+  const int64_t grid = (n + chunk - 1) / chunk;
+  if (grid < 1 || n >= 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, part, part3,
+                     plan.nsplit, plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
+                     FinalOut{i1, d1, i2, d2, ratio, mask, rec}, flags, cnt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int cpw = chunk >= 1024 ? 1 : (int)(1024 / chunk);
+  const int64_t sgrid = (grid + cpw - 1) / cpw;
+  hipLaunchKernelGGL(k_flag_scatter, dim3((unsigned)sgrid), dim3(256), 0, s, flags, cnt, n, chunk,
+                     cpw, list, count);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Upper bound, per row, on the value |c|^2 - 2 x.c that the distance kernel will compute for the
-// row's nearest codeword, from a guess `hint[row]` of that codeword (k-means: the label of the
-// previous iteration).  thr = v_hint + 3 B with B = 129 * 2^-24 * (|c|^2 + 2 |x| |c|), a bound
-// on the rounding error of either way of accumulating the 129 terms of v; the true nearest
-// codeword has exact v <= exact v_hint, so both it and the hinted codeword rank below thr.
+// Upper bound, per row, on the value the search kernel will compute for the row's nearest
+// codeword, from a guess `hint[row]` of that codeword (k-means: the label of the previous
+// iteration).  With v the value of the hinted codeword as computed here and B the rounding bound:
+// the search kernel's value of that codeword is at most v + 2 B, so the kernel's best is, and
+// starting every lane's list at  thr = v + 7 B + band(v)  keeps thr - best above the band the
+// flag test of k_rescore uses: a row whose guess was right and that has no near-tie is not
+// flagged, and every candidate that could matter still lies below thr and is ranked.
 __global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict__ X, int64_t N,
                                                         const float* __restrict__ C, int64_t K,
-                                                        const float* __restrict__ cn,
+                                                        const float* __restrict__ aux,
                                                         const int32_t* __restrict__ hint,
                                                         float* __restrict__ thr) {
   const int sub = threadIdx.x & 15;
   const int64_t stride = (int64_t)gridDim.x * 16;
+  const float* mu = aux + sub * 8;
+  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
   for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
     const int hraw = hint[row];
     const bool ok = hraw >= 0 && hraw < K;
     const int hh = ok ? hraw : 0;
     const float* xrow = X + row * kD + sub * 8;
     const float* crow = C + (int64_t)hh * kD + sub * 8;
-    float dot = 0.f, xn = 0.f;
+    float dot = 0.f, xn = 0.f, xm = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      dot = __builtin_fmaf(xrow[e], crow[e], dot);
-      xn = __builtin_fmaf(xrow[e], xrow[e], xn);
+      const float t = xrow[e] - mu[e];
+      dot = __builtin_fmaf(t, crow[e], dot);
+      xn = __builtin_fmaf(t, t, xn);
+      xm = __builtin_fmaf(t, mu[e], xm);
     }
     dot = group16_sum(dot);
     xn = group16_sum(xn);
+    xm = group16_sum(xm);
     if (sub == 0) {
-      const float c2 = cn[hh];
-      const float v = c2 - 2.f * dot;
-      const float band = 7.689e-6f * (c2 + 2.f * __builtin_sqrtf(xn * c2));
-      thr[row] = ok ? v + 3.f * band + 1e-30f : __builtin_inff();
+      const float v = aux[kAuxNorms + hh] - 2.f * dot;
+      const float bound = error_bound(xn, cn_max, cr2_max);
+      const float sq = __builtin_fmaxf(xn + 2.f * xm + v, 0.f);   // about the squared distance
+      thr[row] = ok ? v + 7.f * bound + kBandSlope * sq + 1e-30f : __builtin_inff();
     }
   }
 }
 
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
-                                 const float* cn_pad, const int32_t* hint, float* thr,
+                                 const float* aux, const int32_t* hint, float* thr,
                                  hipStream_t s) {
   int64_t grid = (n + 15) / 16;
   if (grid > 16384) grid = 16384;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_hint_threshold, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, k, cn_pad,
+  hipLaunchKernelGGL(k_hint_threshold, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, k, aux,
                      hint, thr);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Direct search: sum (x - c)^2 in float32 for every (row, codeword) pair, no norm expansion and
-// therefore no cancellation.  Twice the arithmetic of the matrix-core kernel (a subtraction and an FMA per component) plus the reads, four times its run time, on the vector ALU; it
-// exists as the on-device checker for sizes no CPU oracle can handle and for callers that want
-// distances free of the expansion's rounding.  16 rows per workgroup live in LDS (every lane
-// reads the same row element: a broadcast), every thread walks codewords t, t+256, ... keeping a
-// top-2 per row, and the 256 partial top-2s are folded by (distance, index).
+// therefore no cancellation.  Twice the arithmetic of the matrix-core kernel (a subtraction and an
+// FMA per component) plus the reads, four times its run time, on the vector ALU.  It serves as the
+// whole-input checker (ic_assign_top2_exact) and as the second look at the rows k_rescore flags.
+// 16 rows per group live in LDS (every lane reads the same row element: a broadcast), every thread
+// walks codewords t, t+256, ... keeping a top-2 per row, and the 256 partial top-2s are folded by
+// (distance, index).
+//
+// Rows: `list` (with *count entries) names them, or rows 0 .. n_rows-1 when list is NULL.  The
+// work is cut into (group of 16 rows, piece of the codebook) items that the workgroups of a
+// fixed-size grid walk; the number of pieces per group is chosen ON THE DEVICE from the number of
+// rows (exact_pieces): a handful of flagged rows against a long codebook must not be one
+// workgroup's job, and many rows need no cutting at all.  With more than one piece the partial
+// top-2 of an item (squared distances) goes to `partial` [row][pieces] for k_exact_finish,
+// otherwise the outputs are written directly.  Every loop bound is uniform in the workgroup and
+// known when the kernel starts.
 constexpr int kExactRows = 16;
 
-__global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X, int64_t N,
+// Pieces per group and codewords per piece, the same in k_exact_top2 and k_exact_finish.
+__device__ __forceinline__ int exact_pieces(int64_t n_groups, int grid, int max_pieces, int K,
+                                            int* k_per) {
+  int64_t s = 1;
+  if (max_pieces > 1 && n_groups > 0 && n_groups < grid) {
+    s = grid / n_groups;
+    const int64_t by_len = (K + 255) / 256;   // at least 256 codewords (one per thread) a piece
+    s = s < by_len ? s : by_len;
+    s = s < max_pieces ? s : max_pieces;
+    s = s < 1 ? 1 : s;
+  }
+  const int per = (int)((K + s - 1) / s);
+  *k_per = per;
+  return (K + per - 1) / per;
+}
+
+__global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X, int64_t n_rows,
                                                     const float* __restrict__ C, int K,
-                                                    FinalOutExact fin) {
+                                                    const int32_t* __restrict__ list,
+                                                    const uint32_t* __restrict__ count,
+                                                    int max_pieces,
+                                                    ic_top2_rec* __restrict__ partial,
+                                                    FinalOut fin) {
   __shared__ __attribute__((aligned(16))) float xs[kExactRows][kD];
   __shared__ float rd1[4][kExactRows], rd2[4][kExactRows];
   __shared__ int ri1[4][kExactRows], ri2[4][kExactRows];
-  const int64_t r0 = (int64_t)blockIdx.x * kExactRows;
-  for (int e = threadIdx.x; e < kExactRows * kD; e += 256) {
-    const int64_t r = r0 + e / kD;
-    xs[e / kD][e % kD] = X[(r < N ? r : N - 1) * kD + e % kD];
-  }
-  __syncthreads();
-  float d1[kExactRows], d2[kExactRows];
-  int i1[kExactRows], i2[kExactRows];
+  __shared__ int64_t rows[kExactRows];
+  const int64_t total = list ? (int64_t)*count : n_rows;
+  const int64_t n_groups = (total + kExactRows - 1) / kExactRows;
+  int k_per;
+  const int pieces = exact_pieces(n_groups, (int)gridDim.x, max_pieces, K, &k_per);
+  const int64_t items = n_groups * pieces;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const int64_t g = item / pieces;
+    const int sp = (int)(item - g * pieces);
+    const int k0 = sp * k_per;
+    const int k1 = k0 + k_per < K ? k0 + k_per : K;
+    __syncthreads();   // the previous item's LDS is no longer read
+    if (threadIdx.x < kExactRows) {
+      int64_t t = g * kExactRows + threadIdx.x;
+      t = t < total ? t : total - 1;
+      rows[threadIdx.x] = list ? (int64_t)list[t] : t;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kExactRows * kD / 4; e += 256) {
+      const int r = e / (kD / 4), q = e % (kD / 4);
+      reinterpret_cast<f32x4*>(&xs[r][0])[q] = reinterpret_cast<const f32x4*>(X + rows[r] * kD)[q];
+    }
+    __syncthreads();
+    float d1[kExactRows], d2[kExactRows];
+    int i1[kExactRows], i2[kExactRows];
 #pragma unroll
-  for (int r = 0; r < kExactRows; ++r) {
-    d1[r] = d2[r] = __builtin_inff();
-    i1[r] = i2[r] = -1;
-  }
-  for (int j = threadIdx.x; j < K; j += 256) {
-    const float* crow = C + (int64_t)j * kD;
-    float acc[kExactRows];
+    for (int r = 0; r < kExactRows; ++r) {
+      d1[r] = d2[r] = __builtin_inff();
+      i1[r] = i2[r] = -1;
+    }
+    for (int j = k0 + (int)threadIdx.x; j < k1; j += 256) {
+      const float* crow = C + (int64_t)j * kD;
+      float acc[kExactRows];
 #pragma unroll
-    for (int r = 0; r < kExactRows; ++r) acc[r] = 0.f;
+      for (int r = 0; r < kExactRows; ++r) acc[r] = 0.f;
 #pragma unroll 1
-    for (int ch = 0; ch < kD; ch += 32) {
-      f32x4 cv[8];
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 cv[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + ch + q * 4);
+        for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + blk * 32 + q * 4);
 #pragma unroll
-      for (int r = 0; r < kExactRows; ++r) {
+        for (int r = 0; r < kExactRows; ++r) acc[r] += block32(&xs[r][blk * 32], cv);
+      }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[r][ch + q * 4]);
+      for (int r = 0; r < kExactRows; ++r) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
+    }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = xv[e] - cv[q][e];
-            acc[r] = __builtin_fmaf(t, t, acc[r]);
-          }
+    for (int r = 0; r < kExactRows; ++r) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const float od1 = __shfl_xor(d1[r], off), od2 = __shfl_xor(d2[r], off);
+        const int oi1 = __shfl_xor(i1[r], off), oi2 = __shfl_xor(i2[r], off);
+        top2_merge_pairs(d1[r], i1[r], d2[r], i2[r], od1, oi1, od2, oi2);
+      }
+      if (lane == 0) {
+        rd1[wave][r] = d1[r]; ri1[wave][r] = i1[r];
+        rd2[wave][r] = d2[r]; ri2[wave][r] = i2[r];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kExactRows) {
+      const int r = threadIdx.x;
+      float a1 = rd1[0][r], a2 = rd2[0][r];
+      int j1 = ri1[0][r], j2 = ri2[0][r];
+      for (int w = 1; w < 4; ++w)
+        top2_merge_pairs(a1, j1, a2, j2, rd1[w][r], ri1[w][r], rd2[w][r], ri2[w][r]);
+      const int64_t t = g * kExactRows + r;
+      if (t < total) {
+        if (pieces > 1) {
+          ic_top2_rec rec;
+          rec.d1 = a1; rec.i1 = j1; rec.d2 = a2; rec.i2 = j2;
+          partial[t * pieces + sp] = rec;
+        } else {
+          write_final(fin, rows[r], a1, j1, a2, j2);
         }
       }
     }
-#pragma unroll
-    for (int r = 0; r < kExactRows; ++r) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int r = 0; r < kExactRows; ++r) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float od1 = __shfl_xor(d1[r], off), od2 = __shfl_xor(d2[r], off);
-      const int oi1 = __shfl_xor(i1[r], off), oi2 = __shfl_xor(i2[r], off);
-      top2_merge_pairs(d1[r], i1[r], d2[r], i2[r], od1, oi1, od2, oi2);
+}
+
+// One thread per listed row: fold its pieces by (squared distance, index) -- the same values a
+// whole scan would have compared -- and write the row's outputs.  `search_grid` is the grid
+// k_exact_top2 ran with.
+__global__ __launch_bounds__(256) void k_exact_finish(const int32_t* __restrict__ list,
+                                                      const uint32_t* __restrict__ count,
+                                                      int search_grid, int max_pieces, int K,
+                                                      const ic_top2_rec* __restrict__ partial,
+                                                      FinalOut fin) {
+  const int64_t total = (int64_t)*count;
+  int k_per;
+  const int pieces = exact_pieces((total + kExactRows - 1) / kExactRows, search_grid, max_pieces,
+                                  K, &k_per);
+  if (pieces == 1) return;   // the search wrote the outputs itself
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * 256) {
+    ic_top2_rec b = partial[t * pieces];
+    for (int s = 1; s < pieces; ++s) {
+      const ic_top2_rec o = partial[t * pieces + s];
+      top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
     }
-    if (lane == 0) {
-      rd1[wave][r] = d1[r]; ri1[wave][r] = i1[r];
-      rd2[wave][r] = d2[r]; ri2[wave][r] = i2[r];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < kExactRows) {
-    const int r = threadIdx.x;
-    float a1 = rd1[0][r], a2 = rd2[0][r];
-    int j1 = ri1[0][r], j2 = ri2[0][r];
-    for (int w = 1; w < 4; ++w) top2_merge_pairs(a1, j1, a2, j2, rd1[w][r], ri1[w][r], rd2[w][r], ri2[w][r]);
-    const int64_t row = r0 + r;
-    if (row < N) {
-      const float e1 = __builtin_sqrtf(a1), e2 = __builtin_sqrtf(a2);
-      if (fin.i1) fin.i1[row] = j1;
-      if (fin.d1) fin.d1[row] = e1;
-      if (fin.i2) fin.i2[row] = j2;
-      if (fin.d2) fin.d2[row] = e2;
-      if (fin.mask) fin.mask[row] = (e1 < e2 * fin.ratio) ? 1 : 0;
-    }
+    write_final(fin, list[t], b.d1, b.i1, b.d2, b.i2);
   }
 }
 
@@ -806,7 +1037,24 @@ hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t 
   const int64_t grid = (n + kExactRows - 1) / kExactRows;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_exact_top2, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, (int)k,
-                     FinalOutExact{i1, d1, i2, d2, ratio, mask});
+                     (const int32_t*)nullptr, (const uint32_t*)nullptr, 1, (ic_top2_rec*)nullptr,
+                     FinalOut{i1, d1, i2, d2, ratio, mask, nullptr});
+  return hipGetLastError();
+}
+
+// The second look at the flagged rows.  Their number is only known on the device, so the grid is
+// fixed (kExactGrid workgroups) and the kernels derive the decomposition from *count.
+hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,
+                             const int32_t* list, const uint32_t* count, ic_top2_rec* partial,
+                             int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                             uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
+  const FinalOut fin{i1, d1, i2, d2, ratio, mask, rec};
+  hipLaunchKernelGGL(k_exact_top2, dim3(kExactGrid), dim3(256), 0, s, x, n, c, (int)k, list, count,
+                     kExactGrid, partial, fin);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_exact_finish, dim3(64), dim3(256), 0, s, list, count, kExactGrid,
+                     kExactGrid, (int)k, partial, fin);
   return hipGetLastError();
 }
 
@@ -854,25 +1102,127 @@ hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipSt
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k_copy_pad_inf(const float* __restrict__ src, int64_t k,
-                                                      int64_t kpad, float* __restrict__ dst) {
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < kpad; t += (int64_t)gridDim.x * 256)
-    dst[t] = t < k ? src[t] : __builtin_inff();
+// ---------------------------------------------------------------------------------------------
+// The codebook's auxiliary block (layout: kAux* in ic_internal.h): the mean vector m, the centred
+// squared norms |c_j - m|^2 the search kernel starts its accumulators from, and the two maxima of
+// the rounding model.  Any m would do -- distances do not depend on it -- so its own rounding is
+// of no concern; the sums run in a fixed order, so the block is reproducible.
+constexpr int kAuxSlabMax = 128;
+
+// slab g: column sums of rows [g rows_per_slab, ...) -> psum [slab][128]
+__global__ __launch_bounds__(256) void k_aux_colsum(const float* __restrict__ C, int64_t K,
+                                                    int64_t rows_per_slab,
+                                                    float* __restrict__ psum) {
+  __shared__ f32x4 red[8][32];
+  const int col4 = threadIdx.x & 31, phase = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t r1 = r0 + rows_per_slab < K ? r0 + rows_per_slab : K;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + phase; r < r1; r += 8)
+    acc += reinterpret_cast<const f32x4*>(C + r * kD)[col4];
+  red[phase][col4] = acc;
+  __syncthreads();
+  if (phase == 0) {
+    f32x4 t = red[0][col4];
+    for (int p = 1; p < 8; ++p) t += red[p][col4];
+    reinterpret_cast<f32x4*>(psum + (int64_t)blockIdx.x * kD)[col4] = t;
+  }
 }
 
-hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const float* c_sqnorm,
-                                 float* cn_pad, hipStream_t s) {
-  if (c_sqnorm) {
-    int64_t grid = (kpad + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_copy_pad_inf, dim3((unsigned)grid), dim3(256), 0, s, c_sqnorm, k, kpad,
-                       cn_pad);
-    return hipGetLastError();
+// Every workgroup folds the slab sums into the mean (same order everywhere, so the same bits),
+// then 16 lanes per codeword: centred and raw squared norm; per-workgroup maxima -> pmax.
+__global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, int64_t K,
+                                                   int64_t kpad, const float* __restrict__ psum,
+                                                   int n_slabs, float* __restrict__ aux,
+                                                   float* __restrict__ pmax) {
+  __shared__ float mean[kD];
+  __shared__ float wmax[2][16];
+  if (threadIdx.x < kD) {
+    double t = 0.0;
+    for (int g = 0; g < n_slabs; ++g) t += (double)psum[(int64_t)g * kD + threadIdx.x];
+    const float m = (float)(t / (double)K);
+    mean[threadIdx.x] = m;
+    if (blockIdx.x == 0) aux[threadIdx.x] = m;
   }
-  int64_t grid = (kpad + 15) / 16;
-  if (grid > 16384) grid = 16384;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)grid), dim3(256), 0, s, c, k, kD, kpad, cn_pad);
+  __syncthreads();
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const f32x4 m0 = *reinterpret_cast<const f32x4*>(&mean[sub * 8]);
+  const f32x4 m1 = *reinterpret_cast<const f32x4*>(&mean[sub * 8 + 4]);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  float cmax = 0.f, rmax = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + grp; row < kpad; row += stride) {
+    float cn = __builtin_inff();
+    if (row < K) {
+      const float* cr = C + row * kD + sub * 8;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr);
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+      cn = group16_sum(chain8(c0, c1, m0, m1));
+      const float rn = group16_sum(chain8(c0, c1, zero, zero));
+      cmax = __builtin_fmaxf(cmax, cn);
+      rmax = __builtin_fmaxf(rmax, rn);
+    }
+    if (sub == 0) aux[kAuxNorms + row] = cn;
+  }
+  if (sub == 0) {
+    wmax[0][grp] = cmax;
+    wmax[1][grp] = rmax;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int g = 0; g < 16; ++g) t = __builtin_fmaxf(t, wmax[threadIdx.x][g]);
+    pmax[(int64_t)blockIdx.x * 2 + threadIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_aux_max(const float* __restrict__ pmax, int n,
+                                                float* __restrict__ aux) {
+  float c = 0.f, r = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    c = __builtin_fmaxf(c, pmax[2 * i]);
+    r = __builtin_fmaxf(r, pmax[2 * i + 1]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    c = __builtin_fmaxf(c, __shfl_xor(c, off));
+    r = __builtin_fmaxf(r, __shfl_xor(r, off));
+  }
+  if (threadIdx.x == 0) {
+    aux[kAuxCnMax] = c;
+    aux[kAuxCr2Max] = r;
+  }
+}
+
+static int aux_norm_grid(int64_t kpad) {
+  int64_t g = (kpad + 15) / 16;
+  return (int)(g > 512 ? 512 : (g < 1 ? 1 : g));
+}
+
+size_t codebook_aux_scratch_bytes(int64_t k) {
+  const int64_t kpad = (k + kStageK - 1) / kStageK * kStageK;
+  return (size_t)kAuxSlabMax * kD * 4 + (size_t)aux_norm_grid(kpad) * 2 * 4;
+}
+
+hipError_t launch_codebook_aux(const float* c, int64_t k, float* aux, char* scratch,
+                               hipStream_t s) {
+  const int64_t kpad = (k + kStageK - 1) / kStageK * kStageK;
+  int64_t n_slabs = (k + 63) / 64;
+  if (n_slabs > kAuxSlabMax) n_slabs = kAuxSlabMax;
+  const int64_t rows_per_slab = (k + n_slabs - 1) / n_slabs;
+  n_slabs = (k + rows_per_slab - 1) / rows_per_slab;
+  float* psum = reinterpret_cast<float*>(scratch);
+  float* pmax = psum + (size_t)kAuxSlabMax * kD;
+  hipLaunchKernelGGL(k_aux_colsum, dim3((unsigned)n_slabs), dim3(256), 0, s, c, k, rows_per_slab,
+                     psum);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int grid = aux_norm_grid(kpad);
+  hipLaunchKernelGGL(k_aux_norms, dim3((unsigned)grid), dim3(256), 0, s, c, k, kpad, psum,
+                     (int)n_slabs, aux, pmax);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_aux_max, dim3(1), dim3(64), 0, s, pmax, grid, aux);
   return hipGetLastError();
 }
 

@@ -32,23 +32,44 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n);
 // once per device, with that device current: function attributes of the search kernels
 hipError_t assign_init();
 
+// The codebook's auxiliary block, float [kAuxNorms + kpad] (kpad = k rounded up to kStageK):
+constexpr int kAuxCnMax = 128;    // [0, 128) mean vector m; [128] max_j |c_j - m|^2
+constexpr int kAuxCr2Max = 129;   // [129] max_j |c_j|^2
+constexpr int kAuxNorms = 256;    // [256 + j] = |c_j - m|^2 for j < k, +inf for k <= j < kpad
+// the flagged rows' second look runs on a fixed grid; cut into pieces it holds at most one
+// partial record per (row, piece) with groups x pieces <= the grid, i.e. 16 * kExactGrid records
+constexpr int kExactGrid = 4096;
+
 hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s);
-// cn_pad[j] = |c_j|^2 for j < k (or a copy of c_sqnorm), +inf for k <= j < kpad.
-hipError_t launch_codebook_norms(const float* c, int64_t k, int64_t kpad, const float* c_sqnorm,
-                                 float* cn_pad, hipStream_t s);
+// aux <- auxiliary block of c [k][128]; scratch: codebook_aux_scratch_bytes(k) bytes
+size_t codebook_aux_scratch_bytes(int64_t k);
+hipError_t launch_codebook_aux(const float* c, int64_t k, float* aux, char* scratch,
+                               hipStream_t s);
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
-// part [assign_part_records]: per K-split (cn - 2 x.c, index) best and second best.
+// part [assign_part_records]: per K-split (|c-m|^2 - 2 (x-m).c, index) best and second best;
+// part3 the value of the third best.  mode2: the caller wants the second neighbour too.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* cn_pad, const AssignPlan& plan, const float* thr,
-                               ic_top2_rec* part, hipStream_t s);
+                               const float* aux, const AssignPlan& plan, bool mode2,
+                               const float* thr, ic_top2_rec* part, float* part3, hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
-                                 const float* cn_pad, const int32_t* hint, float* thr,
+                                 const float* aux, const int32_t* hint, float* thr,
                                  hipStream_t s);
-// merge the K-splits, recompute the two distances exactly as sum (x-c)^2, order, sqrt, ratio.
-hipError_t launch_rescore(const float* x, int64_t n, const float* c, const ic_top2_rec* part,
-                          const AssignPlan& plan, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                          uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
+// merge the K-splits, evaluate the two candidates as sum (x-c)^2, order, sqrt, ratio test; flag
+// the rows whose pair is not certain to hold the answer and list them (ascending) with their
+// number.  flags [n] u8, cnt [ceil(n / rescore_chunk(n))] u32, list [n] i32, count [1] u32.
+int64_t rescore_chunk(int64_t n);
+hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
+                          const ic_top2_rec* part, const float* part3, const AssignPlan& plan,
+                          bool mode2, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          uint8_t* mask, ic_top2_rec* rec, uint8_t* flags, uint32_t* cnt,
+                          int32_t* list, uint32_t* count, hipStream_t s);
+// search the listed rows again by direct differences and overwrite their outputs.
+// partial: 16 * kExactGrid records.
+hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,
+                             const int32_t* list, const uint32_t* count, ic_top2_rec* partial,
+                             int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                             uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
 hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t n,
                              const int64_t* shard_base_host, int64_t* i1, float* d1, int64_t* i2,
                              float* d2, float ratio, uint8_t* mask, hipStream_t s);

@@ -26,15 +26,24 @@ def default_device():
 
 
 class ResidentCodebook(object):
-    """float32 codebook [K, D] in HBM together with its squared row norms."""
+    """float32 codebook [K, D] in HBM together with its auxiliary block (mean vector, centred
+    squared norms, error-model maxima: what every search of this codebook needs)."""
 
     def __init__(self, codebook, device=None):
         device = device or default_device()
         self.c = ops.as_device_f32(codebook, device)
         if self.c.dim() != 2:
             raise ValueError("codebook must be 2-D")
-        self.sqnorm = ops.row_sqnorm(self.c)
+        self._aux = None
         self.device = self.c.device
+
+    @property
+    def aux(self):
+        """Computed on first use: rows wider than 128 (histograms searched with ic_knn_rows) never
+        go through the descriptor search and have no such block."""
+        if self._aux is None:
+            self._aux = ops.codebook_aux(self.c)
+        return self._aux
 
     @property
     def shape(self):

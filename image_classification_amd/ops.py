@@ -67,6 +67,28 @@ def row_sqnorm(x):
     return out
 
 
+def codebook_aux(c):
+    """The auxiliary block of a codebook (float32 device tensor): its mean vector, the squared
+    norms about that mean and the two maxima of the search kernel's rounding model.  Computed once
+    per codebook and passed to the assign_* functions as `c_aux`."""
+    _check_2d_f32(c, "codebook")
+    dev = _dev_index(c)
+    lib = _lib.load()
+    aux = torch.empty(int(lib.ic_codebook_aux_floats(c.shape[0])), dtype=torch.float32,
+                      device=c.device)
+    rc = lib.ic_codebook_aux(_lib.handle(dev), _ptr(c), c.shape[0], c.shape[1], _ptr(aux),
+                             _stream_ptr(dev))
+    _lib.check(rc, "ic_codebook_aux")
+    return aux
+
+
+def debug_flagged(device_index, counter):
+    """Test hook: `counter` (uint32/int32 device tensor with one element, or None) receives the
+    number of rows every following search on this device hands to the direct second look."""
+    rc = _lib.load().ic_debug_flagged(_lib.handle(device_index), _ptr(counter))
+    _lib.check(rc, "ic_debug_flagged")
+
+
 def _check_pair(x, c):
     _check_2d_f32(x, "x")
     _check_2d_f32(c, "codebook")
@@ -78,7 +100,7 @@ def _check_pair(x, c):
         raise ValueError("x and codebook live on different devices")
 
 
-def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None, hint=None):
+def assign_top1(x, c, c_aux=None, want_dist=True, out=None, hint=None):
     """idx[i] = argmin_j |x_i - c_j| (lowest j on ties), dist[i] = that Euclidean distance.
     `out` = (idx, dist) preallocated contiguous device tensors (views are fine).
     `hint` = int32 [n] guess of idx (e.g. the labels of the previous k-means iteration): same
@@ -95,17 +117,17 @@ def assign_top1(x, c, c_sqnorm=None, want_dist=True, out=None, hint=None):
         if hint.dtype != torch.int32 or hint.shape[0] != n or hint.device != x.device:
             raise ValueError("hint must be an int32 device tensor with one entry per row of x")
         rc = _lib.load().ic_assign_top1_hint(
-            _lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1], _ptr(c_sqnorm),
+            _lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1], _ptr(c_aux),
             _ptr(hint.contiguous()), _ptr(idx), _ptr(dist), _stream_ptr(dev))
         _lib.check(rc, "ic_assign_top1_hint")
         return idx, dist
     rc = _lib.load().ic_assign_top1(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
-                                    _ptr(c_sqnorm), _ptr(idx), _ptr(dist), _stream_ptr(dev))
+                                    _ptr(c_aux), _ptr(idx), _ptr(dist), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top1")
     return idx, dist
 
 
-def assign_top1_static(x, c, c_sqnorm, out):
+def assign_top1_static(x, c, c_aux, out):
     """assign_top1 through the entry point that allocates nothing (static device scratch, launches
     only).  `out` = (idx int32 [n], dist float32 [n] or None), preallocated by the caller.  Raises
     when the input needs more scratch than the static buffer holds."""
@@ -113,13 +135,13 @@ def assign_top1_static(x, c, c_sqnorm, out):
     dev = _dev_index(x)
     idx, dist = out
     rc = _lib.load().ic_assign_top1_static(_lib.handle(dev), _ptr(x), x.shape[0], _ptr(c),
-                                           c.shape[0], x.shape[1], _ptr(c_sqnorm), _ptr(idx),
+                                           c.shape[0], x.shape[1], _ptr(c_aux), _ptr(idx),
                                            _ptr(dist), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top1_static")
     return idx, dist
 
 
-def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True, out=None):
+def assign_top2(x, c, ratio=0.8, c_aux=None, want_mask=True, out=None):
     """Two nearest rows of c per row of x, ascending (distance, index), and the ratio-test mask.
     `out` = (i1, d1, i2, d2, mask) preallocated contiguous device tensors."""
     _check_pair(x, c)
@@ -134,7 +156,7 @@ def assign_top2(x, c, ratio=0.8, c_sqnorm=None, want_mask=True, out=None):
         d2 = torch.empty(n, dtype=torch.float32, device=x.device)
         mask = torch.empty(n, dtype=torch.uint8, device=x.device) if want_mask else None
     rc = _lib.load().ic_assign_top2(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0], x.shape[1],
-                                    _ptr(c_sqnorm), _ptr(i1), _ptr(d1), _ptr(i2), _ptr(d2),
+                                    _ptr(c_aux), _ptr(i1), _ptr(d1), _ptr(i2), _ptr(d2),
                                     float(ratio), _ptr(mask), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top2")
     return i1, d1, i2, d2, mask
@@ -169,7 +191,7 @@ def _copy_stream(device):
     return s
 
 
-def assign_from_host(x_np, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=True,
+def assign_from_host(x_np, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,
                      chunk_rows=None):
     """Search rows that live in HOST memory (numpy float32 [n, d], C-contiguous).
 
@@ -202,9 +224,9 @@ def assign_from_host(x_np, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=Tr
         xd.record_stream(cur)
         view = tuple(o[lo:hi] if o is not None else None for o in outs)
         if top2:
-            assign_top2(xd, c, ratio, c_sqnorm, out=view)
+            assign_top2(xd, c, ratio, c_aux, out=view)
         else:
-            assign_top1(xd, c, c_sqnorm, want_dist, out=view)
+            assign_top1(xd, c, c_aux, want_dist, out=view)
     return outs
 
 
@@ -238,13 +260,13 @@ def _copy_rows(dst, src):
     np.copyto(dst, src, casting="same_kind")
 
 
-def assign_from_host_parts(parts, c, c_sqnorm=None, top2=False, ratio=0.8, want_dist=True,
+def assign_from_host_parts(parts, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,
                            chunk_rows=None):
     with _staging_lock:
-        return _assign_from_host_parts(parts, c, c_sqnorm, top2, ratio, want_dist, chunk_rows)
+        return _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows)
 
 
-def _assign_from_host_parts(parts, c, c_sqnorm, top2, ratio, want_dist, chunk_rows):
+def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows):
     """Search rows held as a LIST of host arrays (one per image, any float dtype, [n_i, d]).
 
     The reference concatenates such lists on the host before every call; here worker threads
@@ -319,9 +341,9 @@ def _assign_from_host_parts(parts, c, c_sqnorm, top2, ratio, want_dist, chunk_ro
         xd.record_stream(cur)
         view = tuple(o[row0:row0 + rows] if o is not None else None for o in outs)
         if top2:
-            assign_top2(xd, c, ratio, c_sqnorm, out=view)
+            assign_top2(xd, c, ratio, c_aux, out=view)
         else:
-            assign_top1(xd, c, c_sqnorm, want_dist, out=view)
+            assign_top1(xd, c, c_aux, want_dist, out=view)
         row0 += rows
     return outs
 
@@ -378,14 +400,14 @@ def _to_host_staged(t, nbytes):
     return out
 
 
-def assign_top2_rec(x, c, c_sqnorm=None):
+def assign_top2_rec(x, c, c_aux=None):
     """Same search, packed as [n, 4] int32 words = ic_top2_rec {d1, i1, d2, i2} per row."""
     _check_pair(x, c)
     dev = _dev_index(x)
     n = x.shape[0]
     rec = torch.empty((n, 4), dtype=torch.int32, device=x.device)
     rc = _lib.load().ic_assign_top2_rec(_lib.handle(dev), _ptr(x), n, _ptr(c), c.shape[0],
-                                        x.shape[1], _ptr(c_sqnorm), _ptr(rec), _stream_ptr(dev))
+                                        x.shape[1], _ptr(c_aux), _ptr(rec), _stream_ptr(dev))
     _lib.check(rc, "ic_assign_top2_rec")
     return rec
 

@@ -6,8 +6,12 @@
 
 Same argument meaning, return types and error behaviour; the arithmetic runs in float32 on the
 GPU (scipy promotes to the common dtype of its arguments, float64 for the reference's float64
-vocabulary), so distances agree to float32 rounding and indices wherever the best and second
-best codeword are not within float32 rounding of each other.
+vocabulary).  The index returned for a row is the one a direct float32 evaluation of
+sum (x - c)^2 over the whole code book would pick (lowest index on ties): the matrix-core search
+knows the rounding error of the values it ranks by and re-searches, by direct differences, every
+row it cannot decide with certainty.  Against scipy's float64 that leaves only the rounding of
+the direct sum itself: distances agree to about 1e-7 relative, and indices wherever two code
+words are not closer to each other than that.
 """
 import numpy as np
 

@@ -78,14 +78,31 @@ int ic_profile_end(void* handle, double* kernel_ms_sum, int64_t* launches);
  * vision/utils/scene_functions.py:391). */
 int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, void* stream);
 
+/* Auxiliary block of a codebook: its mean vector, the squared norms of the codewords about that
+ * mean and two maxima that bound the search kernel's rounding error.  Every ic_assign_* call
+ * needs it; a caller that searches one codebook many times (a vocabulary, model/features.py:1166;
+ * a logo database, model/robust_matching.py:73-80) computes it once and passes it as `c_aux`
+ * instead of NULL.  It replaces the squared-norm terms scipy's _vq.vq and sklearn's
+ * euclidean_distances recompute on every call.  aux [ic_codebook_aux_floats(k)] f32, device. */
+int64_t ic_codebook_aux_floats(int64_t k);
+int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, void* stream);
+
+/* Test hook, no counterpart in the reference: after every following ic_assign_* call on this
+ * handle the number of rows that took the second, direct look is copied (on the call's stream) to
+ * the device word `count`; NULL switches it off. */
+int ic_debug_flagged(void* handle, uint32_t* count);
+
 /* Nearest codeword per row: idx[i] = argmin_j ||x_i - c_j|| (lowest j on ties), dist[i] = that
  * Euclidean distance.  Replaces scipy.cluster.vq.vq at model/features.py:1166 and
  * vision/facerec/face_indexing.py:141, and argmin(euclidean_distances(..., squared=True)) at
  * vision/utils/scene_functions.py:391.
- *   x [n][d] f32, c [k][d] f32, c_sqnorm [k] f32 or NULL (computed internally),
- *   idx [n] int32, dist [n] f32 or NULL. */
+ *   x [n][d] f32, c [k][d] f32, c_aux = the codebook's auxiliary block from ic_codebook_aux or
+ *   NULL (computed on every call), idx [n] int32, dist [n] f32 or NULL.
+ * Results are those of the direct float32 search (ic_assign_top2_exact) on every row: the
+ * matrix-core pass knows the rounding error of the values it ranks by, and rows it cannot decide
+ * with certainty are searched again by direct differences inside the same call. */
 int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                   const float* c_sqnorm, int32_t* idx, float* dist, void* stream);
+                   const float* c_aux, int32_t* idx, float* dist, void* stream);
 
 /* ic_assign_top1 for callers that cannot allocate.  It has no counterpart in the reference; it
  * exists for code under HIP graph capture, tight serving loops and harnesses that forbid
@@ -99,14 +116,14 @@ int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int6
  * the ceiling).  All calls on one GPU share that array -- from every handle and every stream --
  * so two calls that overlap in time on one GPU race; order them on one stream or with events. */
 int ic_assign_top1_static(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                          const float* c_sqnorm, int32_t* idx, float* dist, void* stream);
+                          const float* c_aux, int32_t* idx, float* dist, void* stream);
 
 /* ic_assign_top1 with a guess of every row's nearest codeword (k-means: the labels of the
  * previous Lloyd iteration inside kmeans2, vision/facerec/face_indexing.py:158).  The result is
  * the same as without the guess; a good guess lets the kernel skip ranking candidates that
  * cannot beat it.  hint [n] int32, values outside [0,k) mean "no guess". */
 int ic_assign_top1_hint(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                        const float* c_sqnorm, const int32_t* hint, int32_t* idx, float* dist,
+                        const float* c_aux, const int32_t* hint, int32_t* idx, float* dist,
                         void* stream);
 
 /* Two nearest index rows per search row, ascending (distance, index), plus the ratio test
@@ -115,7 +132,7 @@ int ic_assign_top1_hint(void* handle, const float* x, int64_t n, const float* c,
  * loop at model/robust_matching.py:81-84.
  *   i2/d2 may be NULL (top-1 only); mask may be NULL; when k == 1, i2 = -1 and d2 = +inf. */
 int ic_assign_top2(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                   const float* c_sqnorm, int32_t* i1, float* d1, int32_t* i2, float* d2,
+                   const float* c_aux, int32_t* i1, float* d1, int32_t* i2, float* d2,
                    float ratio, uint8_t* mask, void* stream);
 
 /* Same contract as ic_assign_top2, computed by direct differences sum (x-c)^2 in float32 on the
@@ -130,7 +147,7 @@ int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c
  * index shard) for a later ic_top2_merge.  No counterpart in the reference: it exists because
  * the index side of model/robust_matching.py:73-80 is sharded over GPUs. */
 int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
-                       const float* c_sqnorm, ic_top2_rec* rec, void* stream);
+                       const float* c_aux, ic_top2_rec* rec, void* stream);
 
 /* Merge per-shard top-2 records: gathered [n_shards][n] records; shard_base (HOST pointer,
  * n_shards int64) is added to each shard's local indices.  Order is (distance, global index).

@@ -150,19 +150,105 @@ def test_planted_matches_ratio_mask():
     _check_top2(x, index)
 
 
-def test_top1_matches_top2_and_row_sqnorm():
+def test_top1_matches_top2_and_codebook_aux():
     x = sift_like(3000, seed=41)
     c = sift_like(300, seed=42)
     xd, cd = _dev(x), _dev(c)
     idx, dist = ops.assign_top1(xd, cd)
     i1, d1, _, _, _ = ops.assign_top2(xd, cd)
     assert torch.equal(idx, i1) and torch.equal(dist, d1)
-    # caller-provided codebook norms give the same result
-    cn = ops.row_sqnorm(cd)
-    idx2, dist2 = ops.assign_top1(xd, cd, cn)
+    # a caller-provided auxiliary block gives the same result
+    aux = ops.codebook_aux(cd)
+    idx2, dist2 = ops.assign_top1(xd, cd, aux)
     assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
-    ref = (c.astype(np.float64) ** 2).sum(1)
-    assert oracle.check_close(cn.cpu().numpy(), ref, rel=1e-6) <= 1e-6
+    # its contents: mean vector, the two maxima, centred squared norms, +inf padding to 128
+    a = aux.cpu().numpy()
+    c64 = c.astype(np.float64)
+    mean = c64.mean(0)
+    assert a.shape[0] == 256 + 384
+    assert oracle.check_close(a[:128], mean, rel=1e-6) <= 1e-6
+    cn = ((c64 - a[:128].astype(np.float64)) ** 2).sum(1)
+    assert oracle.check_close(a[256:256 + 300], cn, rel=1e-5) <= 1e-5
+    assert np.isinf(a[256 + 300:]).all()
+    assert abs(a[128] - cn.max()) <= 1e-5 * cn.max()
+    assert abs(a[129] - (c64 ** 2).sum(1).max()) <= 1e-5 * (c64 ** 2).sum(1).max()
+    # a narrow codebook is padded before its block is taken
+    c36 = _dev(c[:, :36])
+    i36, d36 = ops.assign_top1(_dev(x[:, :36]), c36, ops.codebook_aux(c36))
+    j36, e36 = ops.assign_top1(_dev(x[:, :36]), c36)
+    assert torch.equal(i36, j36) and torch.equal(d36, e36)
+
+
+def _same_as_direct(x, c, ratio=0.8):
+    """The fast path must return what the all-direct search returns, bit for bit, on every row."""
+    xd, cd = _dev(x), _dev(c)
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.debug_flagged(0, counter)
+    try:
+        fast = ops.assign_top2(xd, cd, ratio)
+        torch.cuda.synchronize()
+        flagged2 = int(counter.item())
+        idx, dist = ops.assign_top1(xd, cd)
+        torch.cuda.synchronize()
+        flagged1 = int(counter.item())
+    finally:
+        ops.debug_flagged(0, None)
+    direct = ops.assign_top2_exact(xd, cd, ratio)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("i1", "d1", "i2", "d2", "mask"), fast, direct):
+        bad = int((a != b).sum()) if a.dtype != torch.float32 else int((a.view(torch.int32) != b.view(torch.int32)).sum())
+        assert bad == 0, "%s differs from the direct search on %d of %d rows" % (name, bad, len(a))
+    assert torch.equal(idx, direct[0])
+    assert torch.equal(dist.view(torch.int32), direct[1].view(torch.int32))
+    return flagged1, flagged2
+
+
+def test_fast_path_equals_direct_search_on_descriptor_like_data():
+    f1, f2 = _same_as_direct(sift_like(60_000, n_modes=512, seed=81), sift_like(3000, n_modes=512, seed=82))
+    # only a small share of the rows needs the second look
+    assert f1 < 600 and f2 < 1200, (f1, f2)
+    _same_as_direct(surf_like(20_000, seed=83), surf_like(700, seed=84))
+
+
+def test_fast_path_equals_direct_search_on_offset_data():
+    # the same descriptors far from the origin: norms dwarf distances, which is where a search by
+    # |c|^2 - 2 x.c alone goes wrong
+    x = sift_like(20_000, seed=85) + np.float32(1000.0)
+    c = sift_like(900, seed=86) + np.float32(1000.0)
+    f1, f2 = _same_as_direct(x, c)
+    assert f1 < 2000, f1            # centring keeps the second look rare here too
+    rd, ri = oracle.topk(x, c, 3)
+    idx, _ = ops.assign_top1(_dev(x), _dev(c))
+    must, bad, agree = oracle.check_indices(idx.cpu().numpy(), ri, rd, 0)
+    assert bad == 0 and agree > 0.9999
+
+
+def test_fast_path_equals_direct_search_on_near_ties_and_duplicates():
+    rng = np.random.default_rng(9)
+    # one-dimensional ramps
+    _same_as_direct((rng.standard_normal((5000, 1)) * 300).astype(np.float32),
+                    (rng.standard_normal((430, 1)) * 300).astype(np.float32))
+    # triples of near-duplicate codewords, rows next to them
+    base = sift_like(300, seed=87)
+    c = np.concatenate([base, base + rng.normal(0, 1e-3, base.shape).astype(np.float32),
+                        base + rng.normal(0, 1e-3, base.shape).astype(np.float32)])
+    x = np.concatenate([base[:200] + rng.normal(0, 1e-3, (200, 128)).astype(np.float32),
+                        sift_like(3000, seed=88)])
+    _same_as_direct(x, c)
+    # exact duplicates and integer data (exact ties everywhere): everything is flagged
+    xi = rng.integers(0, 3, size=(4000, 128)).astype(np.float32)
+    ci = rng.integers(0, 3, size=(500, 128)).astype(np.float32)
+    _same_as_direct(xi, np.concatenate([ci, ci, ci[:100]]))
+    # so many flagged rows that the second look does not cut the codebook into pieces (more
+    # 16-row groups than its grid has workgroups): every best is a three-way tie, and the first
+    # 131 072 rows are searched unsplit, so k_rescore cannot settle them from other splits' records
+    xb = rng.integers(0, 2, size=(140_000, 128)).astype(np.float32)
+    cb = rng.integers(0, 2, size=(2800, 128)).astype(np.float32)
+    f1, _ = _same_as_direct(xb, np.concatenate([cb, cb, cb]))
+    assert f1 > 65536
+    # single codeword, two codewords
+    _same_as_direct(sift_like(100, seed=89), sift_like(1, seed=90))
+    _same_as_direct(sift_like(100, seed=89), sift_like(2, seed=90))
 
 
 def test_merge_of_index_shards_equals_unsharded():
@@ -188,7 +274,7 @@ def test_streamed_host_path_equals_device_path():
     x = sift_like(300_001, seed=61)
     c = sift_like(700, seed=62)
     cd = _dev(c)
-    cn = ops.row_sqnorm(cd)
+    cn = ops.codebook_aux(cd)
     idx_d, dist_d = ops.assign_top1(_dev(x), cd, cn)
     idx_h, dist_h = ops.assign_from_host(x, cd, cn, top2=False, chunk_rows=65536)
     torch.cuda.synchronize()
@@ -221,7 +307,7 @@ def test_gathered_parts_path_equals_device_path():
     parts[3] = parts[3].astype(np.float64)
     c = sift_like(600, seed=63)
     cd = _dev(c)
-    cn = ops.row_sqnorm(cd)
+    cn = ops.codebook_aux(cd)
     allx = np.concatenate([p.astype(np.float32) for p in parts])
     ref = ops.assign_top2(_dev(allx), cd, 0.8, cn)
     for chunk in (50_000, 131_072):
@@ -252,7 +338,7 @@ def test_hinted_search_gives_the_same_answer():
     x = sift_like(200_000, seed=71)
     c = sift_like(3000, n_modes=1024, seed=72)
     xd, cd = _dev(x), _dev(c)
-    cn = ops.row_sqnorm(cd)
+    cn = ops.codebook_aux(cd)
     idx, dist = ops.assign_top1(xd, cd, cn)
     rng = np.random.default_rng(1)
     stale_cb = _dev(c + rng.normal(0, 8.0, size=c.shape).astype(np.float32))
@@ -299,9 +385,8 @@ def test_direct_search_vs_oracle(n, k, d):
         assert bad == 0
 
 
-def test_one_dimensional_near_ties_direct_search_is_strict():
-    # rows far closer to their neighbours than float32 resolves from the norms: the matrix-core
-    # path may pick a neighbour inside that resolution, the direct search may not
+def test_one_dimensional_near_ties_are_strict_on_both_paths():
+    # rows far closer to their neighbours than float32 resolves from the norms
     rng = np.random.default_rng(38)
     x = (rng.standard_normal((2059, 1)) * 300).astype(np.float32)
     c = (rng.standard_normal((430, 1)) * 300).astype(np.float32)
@@ -310,9 +395,12 @@ def test_one_dimensional_near_ties_direct_search_is_strict():
     for col, rank in ((0, 0), (2, 1)):
         must, bad, _ = oracle.check_indices(e[col], ri, rd, rank)
         assert bad == 0
+    # the matrix-core path hands such rows to the direct search: the strict rule holds for it too
     f = [t.cpu().numpy() for t in ops.assign_top2(_dev(x), _dev(c), 0.8)]
-    assert oracle.mismatches_outside_f32_band(f[0], x, c, ri, rd, 0) == 0
-    assert oracle.mismatches_outside_f32_band(f[2], x, c, ri, rd, 1) == 0
+    for col, rank in ((0, 0), (2, 1)):
+        must, bad, _ = oracle.check_indices(f[col], ri, rd, rank)
+        assert bad == 0
+        assert np.array_equal(f[col], e[col])
 
 
 def test_errors_are_loud():

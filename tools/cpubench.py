@@ -67,7 +67,7 @@ def main():
         out["gpu_vs_scipy_max_rel_dist_err"] = float(np.max(np.abs(dist - ref_dist) / np.maximum(ref_dist, 1e-30)))
     out["gpu_vq_numpy_in_out_rows_per_s"] = n / best_of(lambda: vq(x, c64), reps=5)
     xd, cd = torch.from_numpy(x).cuda(), torch.from_numpy(c32).cuda()
-    cn = ops.row_sqnorm(cd)
+    cn = ops.codebook_aux(cd)
 
     def resident():
         ops.assign_top1(xd, cd, cn)

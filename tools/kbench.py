@@ -16,7 +16,7 @@ def run(n, k, reps=5):
     dev = torch.device("cuda", 0)
     x = sift_like_device(n, seed=1, device=dev)
     c = sift_like_device(k, seed=2, device=dev)
-    cn = ops.row_sqnorm(c)
+    cn = ops.codebook_aux(c)
     for _ in range(2):
         ops.assign_top1(x, c, cn, want_dist=False)
     torch.cuda.synchronize()
