@@ -171,6 +171,11 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   if (n == 0) return IC_OK;
   if (!x || !c) return fail(IC_EINVAL, "%s: x and c must not be NULL", who);
   if (!i1 && !rec) return fail(IC_EINVAL, "%s: no output buffer given", who);
+  // the kernels read rows, codewords and the auxiliary block 16 bytes at a time
+  if (d == ic::kD && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(c)) & 15))
+    return fail(IC_EINVAL, "%s: x and c must be 16-byte aligned when d = 128", who);
+  if (reinterpret_cast<uintptr_t>(c_aux) & 15)
+    return fail(IC_EINVAL, "%s: c_aux must be 16-byte aligned", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool mode2 = i2 || d2 || mask || rec;   // the second neighbour is part of the answer
 
@@ -390,6 +395,8 @@ int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, 
   if (k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kD)
     return fail(IC_EINVAL, "ic_codebook_aux: bad shape k=%lld d=%d", (long long)k, d);
   if (!c || !aux) return fail(IC_EINVAL, "ic_codebook_aux: NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(aux) & 15) || (d == ic::kD && (reinterpret_cast<uintptr_t>(c) & 15)))
+    return fail(IC_EINVAL, "ic_codebook_aux: aux (and c when d = 128) must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
@@ -459,6 +466,8 @@ int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c
                 (long long)k, d);
   if (n == 0) return IC_OK;
   if (!x || !c || !i1) return fail(IC_EINVAL, "ic_assign_top2_exact: NULL pointer");
+  if (d == ic::kD && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(c)) & 15))
+    return fail(IC_EINVAL, "ic_assign_top2_exact: x and c must be 16-byte aligned when d = 128");
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);

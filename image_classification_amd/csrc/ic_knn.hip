@@ -366,7 +366,10 @@ template <int METRIC, int Q>
 static void launch_few_q(const float* x, int m0, int mq, const float* c, int64_t n, int d,
                          double* out, hipStream_t s) {
   const dim3 grid((unsigned)((n + 4 * kFewR - 1) / (4 * kFewR)));
-  if (d % 4 == 0)
+  // 16-byte loads need rows that start on 16-byte boundaries (a caller may pass a sub-view)
+  const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(c) & 15) == 0;
+  if (vec)
     hipLaunchKernelGGL((k_pairdist_few<METRIC, true, Q>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);
   else
     hipLaunchKernelGGL((k_pairdist_few<METRIC, false, Q>), grid, dim3(256), 0, s, x, m0, mq, c, n, d, out);

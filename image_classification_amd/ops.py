@@ -14,6 +14,17 @@ import torch
 from . import _lib
 
 TOP2_REC_DTYPE = np.dtype([("d1", "<f4"), ("i1", "<i4"), ("d2", "<f4"), ("i2", "<i4")])
+MAX_DESCRIPTOR_DIM = 128   # the matrix-core search contracts over 128 columns (narrower rows are padded)
+
+
+def check_descriptor_dim(d, who):
+    """The descriptor search handles local image descriptors of up to 128 columns (SURF-128 /
+    SIFT).  Wider rows -- e.g. the 1937-column face signatures of vision/facerec/face_indexing.py:25
+    -- are outside this path and are refused here, before anything is launched."""
+    if int(d) > MAX_DESCRIPTOR_DIM:
+        raise ValueError("%s: rows have %d columns, the descriptor search handles at most %d "
+                         "(use ops.knn_rows / ops.pairwise for wider rows)"
+                         % (who, int(d), MAX_DESCRIPTOR_DIM))
 
 
 def _dev_index(t):
@@ -72,6 +83,7 @@ def codebook_aux(c):
     norms about that mean and the two maxima of the search kernel's rounding model.  Computed once
     per codebook and passed to the assign_* functions as `c_aux`."""
     _check_2d_f32(c, "codebook")
+    check_descriptor_dim(c.shape[1], "codebook_aux")
     dev = _dev_index(c)
     lib = _lib.load()
     aux = torch.empty(int(lib.ic_codebook_aux_floats(c.shape[0])), dtype=torch.float32,
@@ -89,11 +101,13 @@ def debug_flagged(device_index, counter):
     _lib.check(rc, "ic_debug_flagged")
 
 
-def _check_pair(x, c):
+def _check_pair(x, c, descriptor_search=True):
     _check_2d_f32(x, "x")
     _check_2d_f32(c, "codebook")
     if x.shape[1] != c.shape[1]:
         raise ValueError("dimension mismatch: x has %d columns, codebook %d" % (x.shape[1], c.shape[1]))
+    if descriptor_search:
+        check_descriptor_dim(x.shape[1], "descriptor search")
     if c.shape[0] < 1:
         raise ValueError("empty codebook")
     if x.device != c.device:
@@ -537,7 +551,7 @@ def pairwise(x, c, metric="euclidean"):
 def knn_rows(x, c, k, metric="euclidean"):
     """(dist float64 [m, k], idx int32 [m, k]): the k rows of c nearest to every row of x,
     ascending by (distance, index)."""
-    _check_pair(x, c)
+    _check_pair(x, c, descriptor_search=False)
     dev = _dev_index(x)
     k = int(k)
     dist = torch.empty((x.shape[0], k), dtype=torch.float64, device=x.device)

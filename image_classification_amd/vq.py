@@ -16,7 +16,7 @@ words are not closer to each other than that.
 import numpy as np
 
 from .backend import default_backend
-from .clustering import kmeans_fit
+from .clustering import MAX_DIM, kmeans_fit
 
 
 def _as_2d(a, name):
@@ -39,6 +39,9 @@ def vq(obs, code_book, check_finite=True, backend=None):
     if obs_a.shape[1] != cb_a.shape[1]:
         raise ValueError("Code book(%d) and obs(%d) should have the same number of features "
                          "(e.g. columns)" % (cb_a.shape[1], obs_a.shape[1]))
+    if obs_a.shape[1] > MAX_DIM:
+        raise ValueError("vq: observations have %d features, this device search handles at most "
+                         "%d (local image descriptors)" % (obs_a.shape[1], MAX_DIM))
     # scipy scans both arrays on the host first.  For a large observation matrix that scan costs
     # more than the whole device search, so it is replaced by a check of the result: with a finite
     # code book, a row holds an inf or NaN exactly when its distance is not finite.

@@ -17,7 +17,9 @@
  *   - a handle owns a grow-only device workspace (partial results, padded norms).  Growing it
  *     synchronises the device once; calls on one handle are serialised by a mutex, so a handle
  *     may be shared by threads.  Handles must not cross fork(): create one per process.
- *   - descriptor dimension d: 1 <= d <= 128 (rows are zero-padded to 128 internally).
+ *   - descriptor dimension d: 1 <= d <= 128 (rows are zero-padded to 128 internally).  With
+ *     d = 128 the descriptor-search entry points (ic_assign_*, ic_codebook_aux) read x and c in
+ *     place, 16 bytes at a time: both must be 16-byte aligned (IC_EINVAL otherwise).
  */
 #ifndef IC_HIP_H
 #define IC_HIP_H

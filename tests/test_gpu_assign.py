@@ -407,7 +407,7 @@ def test_errors_are_loud():
     x = _dev(np.zeros((4, 128)))
     with pytest.raises(ValueError):
         ops.assign_top1(x, _dev(np.zeros((3, 64))))
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError, match="at most 128"):      # refused before any launch
         ops.assign_top1(_dev(np.zeros((4, 200))), _dev(np.zeros((3, 200))))
     with pytest.raises(ValueError):
         ops.assign_top1(x.cpu(), x)

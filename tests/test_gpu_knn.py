@@ -121,3 +121,29 @@ def test_knn_argument_errors():
         ops.knn_rows(x, c, 2, "cosine")
     with pytest.raises(ValueError):
         ops.pairwise(x, _dev(np.zeros((3, 11), np.float32)), "manhattan")
+
+
+def test_rows_that_start_off_a_16_byte_boundary():
+    # a caller may pass a sub-view (base + 4 bytes): the few-row kernel must then use its scalar
+    # loads, as the tiled one does; the descriptor search refuses such rows instead
+    rng = np.random.default_rng(3)
+    m, n, d = 3, 500, 64
+    xa = rng.random((m, d)).astype(np.float32)
+    ca = rng.random((n, d)).astype(np.float32)
+    xbuf = torch.zeros(1 + m * d, dtype=torch.float32, device="cuda")
+    cbuf = torch.zeros(1 + n * d, dtype=torch.float32, device="cuda")
+    x_off = xbuf[1:].view(m, d)
+    c_off = cbuf[1:].view(n, d)
+    x_off.copy_(torch.from_numpy(xa))
+    c_off.copy_(torch.from_numpy(ca))
+    assert x_off.data_ptr() % 16 == 4 and x_off.is_contiguous()
+    for metric in ("manhattan", "euclidean"):
+        d_ref, i_ref = ops.knn_rows(_dev(xa), _dev(ca), 3, metric)
+        d_off, i_off = ops.knn_rows(x_off, c_off, 3, metric)
+        torch.cuda.synchronize()
+        # same neighbours; the scalar-load instantiation groups its partial sums differently
+        assert torch.equal(i_ref, i_off)
+        assert oracle.check_close(d_off.cpu().numpy(), d_ref.cpu().numpy(), rel=1e-6) <= 1e-6
+    x128 = torch.zeros(1 + 4 * 128, dtype=torch.float32, device="cuda")[1:].view(4, 128)
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        ops.assign_top1(x128, torch.zeros((2, 128), dtype=torch.float32, device="cuda"))

@@ -542,3 +542,49 @@ def test_knn_scikit_rejects_what_sklearn_rejects(backend):
     d_ref, i_ref = ref.kneighbors(fit_x[:5], n_neighbors=3)
     d, i = knn.get_neighbors(fit_x[:5], 3)
     assert np.array_equal(i, i_ref) and np.allclose(d, d_ref, atol=1e-6)
+
+
+def test_rows_wider_than_128_are_refused_with_a_value_error(backend):
+    # the 1937-column face signatures of vision/facerec/face_indexing.py:25 are outside this path
+    wide = np.zeros((6, 1937), dtype=np.float32)
+    with pytest.raises(ValueError, match="at most 128"):
+        vq(wide, wide[:2], backend=backend)
+    with pytest.raises(ValueError, match="at most 128"):
+        kmeans2(wide, 2, iter=1, backend=backend)
+    with pytest.raises(ValueError, match="at most 128"):
+        compute_vocab_features(wide[:2], wide, backend=backend)
+    from image_classification_amd.face_indexing import KMeansHashing
+    with pytest.raises(ValueError, match="at most 128"):
+        KMeansHashing(wide[:2], [1, 1], backend=backend).get_hash(wide[0])
+
+
+def test_codebook_fingerprint_sees_every_element():
+    from image_classification_amd.device import _fingerprint
+    rng = np.random.default_rng(0)
+    cb = rng.random((10_000, 128))
+    base = _fingerprint(cb)
+    assert _fingerprint(cb) == base
+    for r, c in ((5, 0), (4999, 77), (9998, 127), (1, 1)):     # rows a strided sample would skip
+        old = cb[r, c]
+        cb[r, c] = np.nextafter(old, 2.0)                      # one bit
+        assert _fingerprint(cb) != base
+        cb[r, c] = old
+    assert _fingerprint(cb) == base
+    view = cb[::2]                                             # non-contiguous arrays hash too
+    assert _fingerprint(view) == _fingerprint(view) != base
+
+
+@pytest.mark.gpu
+def test_codebook_edited_in_place_between_calls_is_seen():
+    # an online codebook update (or re-seeding one empty centroid) between two vq calls
+    rng = np.random.default_rng(1)
+    from image_classification_amd.synthetic import sift_like
+    cb = sift_like(10_000, n_modes=512, seed=3).astype(np.float64)
+    obs = sift_like(500, seed=4)
+    code0, _ = vq(obs, cb)
+    target = 7777                                              # a row no sparse sample would hit
+    assert not np.any(code0[:3] == target)
+    cb[target] = obs[0].astype(np.float64)                     # now the exact nearest of obs[0]
+    code1, dist1 = vq(obs, cb)
+    assert code1[0] == target and dist1[0] == 0.0
+    assert np.array_equal(code1[1:], code0[1:]) or np.mean(code1[1:] == code0[1:]) > 0.99
