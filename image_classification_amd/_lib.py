@@ -64,7 +64,9 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    # IC_AMD_LIBRARY: another build of the same library (A/B timing of kernel variants)
+    return os.environ.get("IC_AMD_LIBRARY") or \
+        os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def load():

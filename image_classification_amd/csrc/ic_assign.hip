@@ -79,18 +79,33 @@ struct Stage {
 constexpr int kXT = 1;
 constexpr int kSmallCodebook = 8192;   // below this: two 8-wave workgroups per CU
 
-// K-split that finishes `row_tiles` row tiles soonest on `num_cus` workgroup slots.
-static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
-  const double overhead = 2.0;  // x-tile load + pipeline fill, in units of one stage of work
+// K-split that finishes `row_tiles` row tiles soonest, in units of one stage of work.
+//
+// One 16-wave workgroup per CU (large codebooks): workgroups run in rounds of `slots`, each
+// paying its row-tile load and pipeline fill in the open (about two stages' worth).
+//
+// Two 8-wave workgroups per CU: the matrix pipe is shared, so a CU's time is the work it is
+// given, a workgroup's start-up hides behind its neighbour's multiplies (about 0.6 of a stage
+// stays visible, mostly the reload of the row tile), and workgroups start as others finish, so
+// the machine drains within about one item of the ideal.  Measured on 100 000 x 1000 (391 row
+// tiles on 512 slots): unsplit 0.297 ms, 4 pieces 0.281, 6 pieces 0.263, 16 pieces 0.362.
+static int choose_nsplit(int64_t row_tiles, int64_t stages, int slots, bool two_per_cu) {
   int best = 1;
   double best_cost = 1e300;
   const int64_t max_ns = stages < 256 ? stages : 256;
   for (int64_t ns = 1; ns <= max_ns; ++ns) {
-    const int64_t per = (stages + ns - 1) / ns;
-    if ((stages + per - 1) / per != ns) continue;  // same per-split length as a smaller ns
-    const int64_t items = row_tiles * ns;
-    const int64_t rounds = (items + num_cus - 1) / num_cus;
-    const double cost = (double)rounds * ((double)per + overhead) * (1.0 + 0.002 * (double)ns);
+    const int64_t longest = (stages + ns - 1) / ns;   // pieces differ by at most one stage
+    double cost;
+    if (two_per_cu) {
+      if (longest < 2 && stages >= 2) continue;       // one-stage pieces only reload row tiles
+      const double ovh = 0.6;
+      const double work = (double)row_tiles * ((double)stages + (double)ns * ovh);
+      cost = work / (0.5 * slots) + 0.7 * ((double)longest + ovh);
+    } else {
+      const double ovh = 2.0;
+      const int64_t rounds = (row_tiles * ns + slots - 1) / slots;
+      cost = (double)rounds * ((double)longest + ovh) * (1.0 + 0.002 * (double)ns);
+    }
     if (cost < best_cost * 0.999) {
       best_cost = cost;
       best = (int)ns;
@@ -99,10 +114,10 @@ static int choose_nsplit(int64_t row_tiles, int64_t stages, int num_cus) {
   return best;
 }
 
-// One workgroup occupies a CU.  Row tiles that fill whole rounds of the machine are searched over
-// the entire codebook by one workgroup each (the longer a lane's scan, the rarer a tile improves
-// its top-2, so ranking gets cheaper, and X is read once); only the row tiles of the last, partly
-// filled round are split along K so that their pieces spread over all CUs.
+// Row tiles that fill whole rounds of the machine are searched over the entire codebook by one
+// workgroup each (the longer a lane's scan, the rarer a tile improves its top-2, so ranking gets
+// cheaper, and X is read once); only the row tiles of the last, partly filled round are split
+// along K so that their pieces spread over all CUs.
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
   // IC_AMD_GEOMETRY forces a shape (1 = two 8-wave workgroups per CU, 2 = one of 16; tuning aid)
   static const int geom = [] {
@@ -128,12 +143,13 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
   } else {
     p->full_tiles = p->row_tiles / slots * slots;
     const int64_t rem = p->row_tiles - p->full_tiles;
-    ns = rem > 0 ? choose_nsplit(rem, stages, slots) : 1;
+    ns = rem > 0 ? choose_nsplit(rem, stages, slots, small) : 1;
   }
   if (ns > stages) ns = (int)stages;
   if (ns < 1) ns = 1;
-  p->stages_per_split = (int)((stages + ns - 1) / ns);
-  p->nsplit = (int)((stages + p->stages_per_split - 1) / p->stages_per_split);
+  p->nsplit = ns;
+  p->split_base = (int)(stages / ns);     // piece sp covers split_base (+1 for sp < split_extra)
+  p->split_extra = (int)(stages % ns);    // stages, in order
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,8 +389,8 @@ __device__ __forceinline__ int64_t part_slot(int sp, int64_t r, int64_t N, int64
 template <int XT, int NW, int SK, bool GATED, bool MODE2>
 __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
-    const float* __restrict__ aux, int stages_total, int stages_per_split, int full_tiles,
-    int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
+    const float* __restrict__ aux, int stages_total, int split_base, int split_extra,
+    int full_tiles, int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
     float* __restrict__ part3) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -389,12 +405,18 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const int idx = (int)blockIdx.x - full_tiles;
     rt = full_tiles + idx % split_tiles;
     sp = idx / split_tiles;
-    st0 = sp * stages_per_split;
-    st1 = st0 + stages_per_split;
-    st1 = st1 < stages_total ? st1 : stages_total;
+    st0 = sp * split_base + (sp < split_extra ? sp : split_extra);
+    st1 = st0 + split_base + (sp < split_extra ? 1 : 0);
   }
 
-  // descriptors of this wave, 64 components per lane.  Their loads go out first, then the first
+  // The codebook mean travels through a slot of LDS private to the wave (512 bytes behind the
+  // stage buffers): its load is the first one issued, so it has landed long before the rows, and
+  // nothing issued after the stage loads has to be waited for before the first MFMA.
+  float* mu_lds = reinterpret_cast<float*>(smem + 2 * Stage<SK>::kBytes) + wave * kD;
+  f32x4 mu_in = {0.f, 0.f, 0.f, 0.f};
+  if (lane < 32) mu_in = reinterpret_cast<const f32x4*>(aux)[lane];
+
+  // descriptors of this wave, 64 components per lane.  Their loads go out next, then the first
   // two stages of the codebook.
   const int64_t row0 = (int64_t)rt * (XT * NW * 32) + (int64_t)wave * (XT * 32);
   f32x4 xv[XT][16];
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
 #pragma unroll
     for (int q = 0; q < 16; ++q) xv[xt][q] = p[2 * q];
   }
+  if (lane < 32) reinterpret_cast<f32x4*>(mu_lds)[lane] = mu_in;
   issue_stage<NW, SK>(C, K, cnp, st0, smem, wave, lane);
   const bool two = st0 + 1 < st1;
   if (two) issue_stage<NW, SK>(C, K, cnp, st0 + 1, smem + Stage<SK>::kBytes, wave, lane);
@@ -415,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
   float xr[XT][64];
   float c0[XT];
   {
-    const f32x4* mp = reinterpret_cast<const f32x4*>(aux + h * 4);
+    const f32x4* mp = reinterpret_cast<const f32x4*>(mu_lds + h * 4);
 #pragma unroll
     for (int xt = 0; xt < XT; ++xt) {
       float xn = 0.f, xm = 0.f;
@@ -537,18 +560,18 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   auto kern = !gated_variant() ? k_top2_partial<kXT, NW, SK, false, false>
               : mode2 ? k_top2_partial<kXT, NW, SK, true, true>
                       : k_top2_partial<kXT, NW, SK, true, false>;
-  const int lds = 2 * Stage<SK>::kBytes;   // allowed by assign_init() on this device
+  const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // allowed by assign_init() on this device
   const int64_t grid = plan.full_tiles + split_tiles * plan.nsplit;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
-                     (int)stages, plan.stages_per_split, (int)plan.full_tiles, (int)split_tiles,
-                     thr, part, part3);
+                     (int)stages, plan.split_base, plan.split_extra, (int)plan.full_tiles,
+                     (int)split_tiles, thr, part, part3);
   return hipGetLastError();
 }
 
 template <int NW, int SK>
 static hipError_t allow_lds() {
-  const int lds = 2 * Stage<SK>::kBytes;
+  const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // two stage buffers + a mean vector per wave
   const void* kerns[3] = {reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, false, false>),
                           reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, true, false>),
                           reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, true, true>)};

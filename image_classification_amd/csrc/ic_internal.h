@@ -19,11 +19,11 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 // Decomposition of one search.  Geometry: workgroups of `waves` waves hold rows_per_wg rows in
 // registers and stream the codebook through LDS in stages of stage_k codewords.  The first
 // full_tiles row tiles are scanned over the whole codebook by one workgroup each, the remaining
-// ones in nsplit K-splits of stages_per_split stages.
+// ones in nsplit K-splits whose lengths differ by at most one stage.
 struct AssignPlan {
   int waves, stage_k, rows_per_wg;
   int64_t row_tiles, full_tiles;
-  int nsplit, stages_per_split;
+  int nsplit, split_base, split_extra;
 };
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p);
 // records the partial buffer of a plan holds: one per row, plus nsplit - 1 more for every row of
