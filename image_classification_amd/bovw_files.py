@@ -14,8 +14,22 @@ File contract (all citations relative to the reference tree):
 `vocab_kms(bin_dir, in_file_projection, in_vocab_size, out_file)` keeps the signature and the guard
 of the wrapper at vision/utils/bovw_functions.py:111-119.  The binary it wraps is not part of the
 reference, so its k-means variant (initialisation, iteration count, empty-cluster rule) is unknown;
-this stand-in uses the kmeans2 semantics of clustering.py.  `hist_kms` is not provided: its output
-is an OpenCV matrix file whose row layout (labels, ids) is produced inside the missing binary.
+this stand-in uses the kmeans2 semantics of clustering.py.
+
+`hist_kms(bin_dir, in_file_vocab, in_file_projection, out_file)` keeps the signature of the wrapper
+at vision/utils/bovw_functions.py:122-130 (argv of the binary: vocabulary, descriptors, output).
+Its source is missing too; what IS in the reference are the readers of its output
+(`svm_model` / `predict`, vision/utils/bovw_functions.py:133-159): the file is one OpenCV matrix,
+loaded whole with `cv.Load(path)`, one row per image =
+    [label, hist_0 .. hist_{K-1}, video_id, timestamp]
+(`hist[:, 0]` labels, `hist[:, 1:-2]` features, `hist[:, -2:]` metadata).  The format written
+here is derived from those readers; the node name, the float32 element type, the L1 normalisation
+(the rule of the only in-repo histogram, model/features.py:1178-1179) and the way image
+boundaries, labels and ids reach the binary are not documented anywhere in the reference, so that
+part of the contract is unpinned.  Image boundaries come from an `nImg` tag (equal image sizes,
+as dense-grid extraction produces and compute_spatial_features_from_xml assumes,
+vision/utils/scene_functions.py:330-334) or an `imageOffsets` matrix; labels and ids from optional
+`labels` / `ids` matrices of the descriptor file, zeros otherwise.
 """
 import os
 import sys
@@ -25,10 +39,11 @@ from xml.sax.saxutils import XMLGenerator
 import numpy as np
 
 __all__ = ["write_descriptor_file", "read_descriptor_file", "write_vocab_file", "read_vocab_file",
-           "extract_from_xml", "binary_to_ndarray", "vocab_kms"]
+           "extract_from_xml", "binary_to_ndarray", "vocab_kms", "hist_kms", "write_opencv_matrix",
+           "load_opencv_matrix", "load_first_opencv_matrix"]
 
 
-def _write_tags(xml_file, tags):
+def _write_tags(xml_file, tags, matrices=()):
     with open(xml_file, "w") as out:
         w = XMLGenerator(out=out, encoding="utf-8")
         w.startDocument()
@@ -37,8 +52,42 @@ def _write_tags(xml_file, tags):
             w.startElement(name, {})
             w.characters(str(value))
             w.endElement(name)
+        for name, mat in matrices:
+            _write_matrix_node(w, name, mat)
         w.endElement("opencv_storage")
         w.endDocument()
+
+
+_DT = {"u": np.uint8, "c": np.int8, "w": np.uint16, "s": np.int16, "i": np.int32,
+       "f": np.float32, "d": np.float64}
+
+
+def _write_matrix_node(w, name, mat):
+    """One `type_id="opencv-matrix"` node: <rows>, <cols>, <dt>, whitespace-separated <data>."""
+    mat = np.asarray(mat)
+    if mat.ndim == 1:
+        mat = mat[:, None]
+    dt = [k for k, v in _DT.items() if np.dtype(v) == mat.dtype]
+    if not dt:
+        mat = mat.astype(np.float64)
+        dt = ["d"]
+    fmt = "%d" if mat.dtype.kind in "iu" else ("%.8e" if mat.dtype == np.float32 else "%.17e")
+    w.startElement(name, {"type_id": "opencv-matrix"})
+    for tag, value in (("rows", mat.shape[0]), ("cols", mat.shape[1]), ("dt", dt[0])):
+        w.startElement(tag, {})
+        w.characters(str(value))
+        w.endElement(tag)
+    w.startElement("data", {})
+    for row in mat:
+        w.characters("\n    " + " ".join(fmt % v for v in row))
+    w.endElement("data")
+    w.endElement(name)
+
+
+def write_opencv_matrix(xml_file, name, mat, tags=()):
+    """An OpenCV XML storage file holding one matrix node (and optional integer tags)."""
+    _write_tags(xml_file, list(tags), [(name, mat)])
+    return xml_file
 
 
 def write_descriptor_file(xml_file, feats):
@@ -82,11 +131,22 @@ def load_opencv_matrix(path, name):
     cols = int(node.find("cols").text)
     dt = node.find("dt").text.strip().strip('"')
     channels = int(dt[:-1]) if len(dt) > 1 else 1
-    kinds = {"u": np.uint8, "c": np.int8, "w": np.uint16, "s": np.int16, "i": np.int32,
-             "f": np.float32, "d": np.float64}
+    kinds = _DT
     assert dt[-1] in kinds, "unknown OpenCV element type %r" % dt
     data = np.array(node.find("data").text.split(), dtype=np.float64).astype(kinds[dt[-1]])
     return data.reshape(rows, cols, channels)
+
+
+def load_first_opencv_matrix(path):
+    """The first matrix node of an OpenCV XML storage file as a 2-D ndarray: what
+    `np.asarray(cv.Load(path))` gives for a single-channel matrix
+    (vision/utils/bovw_functions.py:134,149)."""
+    root = ElementTree.parse(path).getroot()
+    for node in root:
+        if node.get("type_id") == "opencv-matrix":
+            m = load_opencv_matrix(path, node.tag)
+            return m[:, :, 0] if m.shape[2] == 1 else m
+    raise AssertionError("no opencv-matrix node in %s" % path)
 
 
 def binary_to_ndarray(filename, dims, dtype):
@@ -142,9 +202,70 @@ def vocab_kms(bin_dir, in_file_projection, in_vocab_size, out_file, iterations=2
     return out_file
 
 
+def _image_offsets(xml_file, n_desc):
+    """Image boundaries of a descriptor file: `imageOffsets` matrix, else `nImg` equal images,
+    else one image."""
+    root = ElementTree.parse(xml_file).getroot()
+    if root.find("imageOffsets") is not None:
+        off = load_opencv_matrix(xml_file, "imageOffsets").reshape(-1).astype(np.int64)
+        if off[0] != 0 or off[-1] != n_desc or np.any(np.diff(off) < 0):
+            raise IOError("imageOffsets of %s must rise from 0 to nDescriptors" % xml_file)
+        return off
+    n_img = int(root.find("nImg").text) if root.find("nImg") is not None else 1
+    if n_img < 1 or n_desc % n_img:
+        raise IOError("%d descriptors do not divide into %d images" % (n_desc, n_img))
+    return np.arange(n_img + 1, dtype=np.int64) * (n_desc // n_img)
+
+
+def hist_kms(bin_dir, in_file_vocab, in_file_projection, out_file, norm="l1", backend=None):
+    """Assign every descriptor of the projection file to its nearest vocabulary word and write
+    one histogram row per image: [label, K bins, video_id, timestamp] (see the module docstring).
+
+    `bin_dir` is accepted for signature compatibility and ignored.
+    """
+    from .backend import default_backend
+    for f in (in_file_vocab, in_file_projection):
+        _verify_readable(f)
+    _verify_writable(out_file)
+    vocab = read_vocab_file(in_file_vocab)
+    feats = read_descriptor_file(in_file_projection)
+    if feats.shape[1] != vocab.shape[1]:
+        raise IOError("descriptors have %d columns, the vocabulary %d"
+                      % (feats.shape[1], vocab.shape[1]))
+    offsets = _image_offsets(in_file_projection, feats.shape[0])
+    n_img = len(offsets) - 1
+    b = backend or default_backend()
+    if feats.shape[0]:
+        codes, _ = b.assign_top1_np(feats, b.codebook(vocab), want_dist=False)
+    else:
+        codes = b.i32(np.empty(0, dtype=np.int32))
+    hists = b.to_host(b.hist(codes, b.i64(offsets), vocab.shape[0], norm))
+    root = ElementTree.parse(in_file_projection).getroot()
+    labels = np.zeros(n_img)
+    ids = np.zeros((n_img, 2))
+    if root.find("labels") is not None:
+        labels = load_opencv_matrix(in_file_projection, "labels").reshape(-1).astype(np.float64)
+    if root.find("ids") is not None:
+        ids = load_opencv_matrix(in_file_projection, "ids").reshape(n_img, 2).astype(np.float64)
+    if labels.shape[0] != n_img:
+        raise IOError("%d labels for %d images" % (labels.shape[0], n_img))
+    rows = np.concatenate([labels[:, None], np.asarray(hists, dtype=np.float64), ids], axis=1)
+    write_opencv_matrix(out_file, "hist", rows.astype(np.float32))
+    return out_file
+
+
 def main(argv=None):
-    """argv of the binary: vocab_kms <in.xml> <out.xml> <vocab_size>."""
-    argv = sys.argv[1:] if argv is None else argv
+    """argv of the binaries: [vocab_kms] <in.xml> <out.xml> <vocab_size>, or
+    hist_kms <vocab.xml> <descriptors.xml> <out.xml>."""
+    argv = sys.argv[1:] if argv is None else list(argv)
+    if argv and argv[0] == "hist_kms":
+        if len(argv) != 4:
+            sys.stderr.write("usage: hist_kms <vocab.xml> <descriptors.xml> <hist.xml>\n")
+            return 2
+        hist_kms(None, argv[1], argv[2], argv[3])
+        return 0
+    if argv and argv[0] == "vocab_kms":
+        argv = argv[1:]
     if len(argv) != 3:
         sys.stderr.write("usage: vocab_kms <descriptors.xml> <vocab.xml> <vocab_size>\n")
         return 2

@@ -13,8 +13,9 @@ one device call builds every histogram.
 `norm` is an extension: 'l1' is the reference's normalisation, 'l2', 'power_l2' and 'none' are
 additional modes with no counterpart in the reference.
 """
+import importlib
+import json
 import os
-import pickle
 
 import numpy as np
 
@@ -85,42 +86,57 @@ class Vocabulary(object):
 
 
 class BagOfWords(object):
+    """Bag-of-words quantiser with the reference's constructor, `train` and `extract`
+    (model/features.py:1125-1212).
+
+    Model directories are this package's own design, not the reference's pickled class table
+    (model/features.py:1218-1268): `save_to_dir` writes `bow.json` (a manifest: format version,
+    normalisation, the import paths of the extractor / projection classes, any subclass
+    parameters) next to `vocab.npy` -- the one file both layouts share -- and lets the extractor
+    and the projection write their own files through their `save_to_file`.  `load_from_dir`
+    imports the classes named in the manifest and calls their `load_from_file`; nothing is
+    unpickled.  A directory written by the reference (no manifest) still yields its vocabulary:
+    pass the extractor (and projection) objects to `load_from_dir` in that case.
+    """
+    MANIFEST = "bow.json"
+    VOCAB_FILE = "vocab.npy"
+    _component_files = {"feat_ext": "feat_ext", "projection": "project"}
+    _extra_params = ()          # attribute names a subclass wants in the manifest
 
     def __init__(self, feat_ext, vocabsize=None, vocab=None, projection=None, norm="l1",
                  power=0.5, backend=None):
-        self.feat_ext = feat_ext
         assert hasattr(feat_ext, "extract")
-        self.projection = projection
-        if self.projection:
-            assert hasattr(projection, "train")
-            assert hasattr(projection, "project")
-        if vocab is not None:
-            self.vocabsize = len(vocab)
-        else:
+        if projection:
+            assert hasattr(projection, "train") and hasattr(projection, "project")
+        if vocab is None:
             assert vocabsize, "Vocabsize required for training"
-            self.vocabsize = vocabsize
+        self.feat_ext = feat_ext
+        self.projection = projection
         self.vocab = vocab
+        self.vocabsize = len(vocab) if vocab is not None else vocabsize
         self.norm = norm
         self.power = power
         self._backend = backend
 
-    # -- helpers -------------------------------------------------------------------------------
     def _b(self):
         return getattr(self, "_backend", None) or default_backend()
 
-    def _learn_projection(self, all_feats):
-        self.projection.train(all_feats)
+    # -- descriptors -----------------------------------------------------------------------------
+    def _describe(self, image_list, fit_projection=False):
+        """Extractor output as ImageDescs, projected when a projection is configured (fitted on
+        all descriptors of the call first when `fit_projection`)."""
+        descs = [ImageDesc(*r) for r in self.feat_ext.extract(image_list)]
+        if not self.projection:
+            return descs
+        if fit_projection:
+            self.projection.train(self._stack(descs))
+        return [ImageDesc(d.cv_keypoints,
+                          None if d.descriptors is None else self.projection.project(d.descriptors))
+                for d in descs]
 
-    def _project(self, image_descs):
-        projected_descs = []
-        for i in image_descs:
-            if i.descriptors is not None:
-                proj_feats = self.projection.project(i.descriptors)
-                desc = ImageDesc(i.cv_keypoints, proj_feats)
-            else:
-                desc = ImageDesc(i.cv_keypoints, None)
-            projected_descs.append(desc)
-        return projected_descs
+    @staticmethod
+    def _stack(image_descs):
+        return np.concatenate([d.descriptors for d in image_descs if d.descriptors is not None])
 
     def _learn_vocab(self, all_feats):
         self._vocab_trainer = Vocabulary(self.vocabsize, backend=getattr(self, "_backend", None))
@@ -182,88 +198,74 @@ class BagOfWords(object):
                        self.norm, self.power)
         return hists.cpu().numpy()
 
-    def _feature_extract(self, image_list):
-        results = self.feat_ext.extract(image_list)
-        return [ImageDesc(*r) for r in results]
-
-    def _merge_descs_to_feats(self, image_descs):
-        return np.concatenate([i.descriptors for i in image_descs if i.descriptors is not None])
-
     def train(self, image_list):
-        image_descs = self._feature_extract(image_list)
-        if self.projection:
-            all_feats = self._merge_descs_to_feats(image_descs)
-            self._learn_projection(all_feats)
-            image_descs = self._project(image_descs)
+        """Fit the projection (if any) and the vocabulary (if none was given) on the images, then
+        quantise them: (image_descs, hists), as model/features.py:1192-1204 returns."""
+        image_descs = self._describe(image_list, fit_projection=True)
         if self.vocab is None:
-            all_feats = self._merge_descs_to_feats(image_descs)
-            self.vocab = self._learn_vocab(all_feats)
+            self._learn_vocab(self._stack(image_descs))
         return self._quantize(image_descs)
 
     def extract(self, image_list):
-        image_descs = self._feature_extract(image_list)
-        if self.projection:
-            image_descs = self._project(image_descs)
-        return self._quantize(image_descs)
+        """(image_descs, hists float64 [n_images, vocabsize]) as model/features.py:1206-1212."""
+        return self._quantize(self._describe(image_list))
 
-    # -- model directory (vocab.npy is the codebook's on-disk format, model/features.py:1218-1268)
+    # -- model directory -------------------------------------------------------------------------
     def save_to_dir(self, model_dir):
         assert self.vocab is not None, "vocab is not set"
-        if not os.path.isdir(model_dir):
-            os.makedirs(model_dir)
-        class_dict = {}
-        if self.projection:
-            self.projection.save_to_file(self._proj_path(model_dir))
-            class_dict["project"] = self.projection.__class__
-        np.save(self._vocab_path(model_dir), self.vocab)
-        self.feat_ext.save_to_file(self._feat_path(model_dir))
-        class_dict["feat_ext"] = self.feat_ext.__class__
-        with open(self._class_path(model_dir), "wb") as f:
-            pickle.dump(class_dict, f)
-
-    @staticmethod
-    def get_state(model_dir):
-        cls = BagOfWords
-        with open(cls._class_path(model_dir), "rb") as f:
-            class_dict = pickle.load(f)
-        feat_ext = class_dict["feat_ext"].load_from_file(cls._feat_path(model_dir))
-        projection = None
-        if "project" in class_dict:
-            projection = class_dict["project"].load_from_file(cls._proj_path(model_dir))
-        vocab = np.load(cls._vocab_path(model_dir))
-        return dict(vocab=vocab, vocabsize=len(vocab), feat_ext=feat_ext, projection=projection)
+        os.makedirs(model_dir, exist_ok=True)
+        manifest = {"format": 1, "class": _import_path(type(self)), "norm": self.norm,
+                    "power": self.power, "components": {},
+                    "params": {name: getattr(self, name) for name in self._extra_params}}
+        for attr, fname in self._component_files.items():
+            obj = getattr(self, attr)
+            if obj:
+                obj.save_to_file(os.path.join(model_dir, fname))
+                manifest["components"][attr] = _import_path(type(obj))
+        np.save(os.path.join(model_dir, self.VOCAB_FILE), np.asarray(self.vocab))
+        with open(os.path.join(model_dir, self.MANIFEST), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
 
     @classmethod
-    def load_from_dir(cls, model_dir):
-        state = cls.get_state(model_dir)
+    def load_from_dir(cls, model_dir, feat_ext=None, projection=None, backend=None):
+        vocab = np.load(os.path.join(model_dir, cls.VOCAB_FILE), allow_pickle=False)
+        manifest = {"norm": "l1", "power": 0.5, "components": {}, "params": {}}
+        path = os.path.join(model_dir, cls.MANIFEST)
+        if os.path.exists(path):
+            with open(path) as f:
+                manifest.update(json.load(f))
+        given = {"feat_ext": feat_ext, "projection": projection}
+        for attr, fname in cls._component_files.items():
+            if given[attr] is None and attr in manifest["components"]:
+                klass = _resolve(manifest["components"][attr])
+                given[attr] = klass.load_from_file(os.path.join(model_dir, fname))
+        if given["feat_ext"] is None:
+            raise ValueError("%s names no feature extractor: pass feat_ext=" % model_dir)
         obj = cls.__new__(cls)
-        vars(obj).update(state)
-        obj.norm = "l1"
-        obj.power = 0.5
-        obj._backend = None
+        BagOfWords.__init__(obj, given["feat_ext"], vocab=vocab, projection=given["projection"],
+                            norm=manifest["norm"], power=manifest["power"], backend=backend)
+        for name in cls._extra_params:
+            setattr(obj, name, manifest["params"][name])
         return obj
 
-    @staticmethod
-    def _class_path(model_dir):
-        return os.path.join(model_dir, "class_file")
 
-    @staticmethod
-    def _proj_path(model_dir):
-        return os.path.join(model_dir, "project")
+def _import_path(klass):
+    return "%s:%s" % (klass.__module__, klass.__qualname__)
 
-    @staticmethod
-    def _vocab_path(model_dir):
-        return os.path.join(model_dir, "vocab.npy")
 
-    @staticmethod
-    def _feat_path(model_dir):
-        return os.path.join(model_dir, "feat_ext")
+def _resolve(path):
+    """'package.module:Class.Inner' -> the class object (importlib, no pickle)."""
+    module, _, qual = path.partition(":")
+    obj = importlib.import_module(module)
+    for part in qual.split("."):
+        obj = getattr(obj, part)
+    return obj
 
 
 class SpatialBagOfWords(BagOfWords):
     """Bag of words with a spatial pyramid (model/features.py:1287-1326): every image has the same
     keypoint grid, and the histogram is `compute_spatial_features` over the codes of all images."""
-    _attrs_to_save = ["n_levels", "im_height", "im_width"]
+    _extra_params = ("n_levels", "im_height", "im_width")
 
     def __init__(self, n_levels, im_height, im_width, feat_ext, vocabsize=None, vocab=None,
                  projection=None, backend=None):
@@ -283,20 +285,3 @@ class SpatialBagOfWords(BagOfWords):
                                             self.n_levels, self.im_width, self.im_height,
                                             backend=getattr(self, "_backend", None))
         return []
-
-    def save_to_dir(self, model_dir):
-        super(SpatialBagOfWords, self).save_to_dir(model_dir)
-        params = {attr: getattr(self, attr) for attr in self._attrs_to_save}
-        with open(self._params_path(model_dir), "wb") as f:
-            pickle.dump(params, f)
-
-    @classmethod
-    def get_state(cls, model_dir):
-        state = BagOfWords.get_state(model_dir)
-        with open(SpatialBagOfWords._params_path(model_dir), "rb") as f:
-            state.update(pickle.load(f))
-        return state
-
-    @staticmethod
-    def _params_path(model_dir):
-        return os.path.join(model_dir, "params")

@@ -95,3 +95,43 @@ def test_spatial_features_from_xml_files(backend, tmp_path):
     ref = oracle.compute_spatial_features(codes, kps, k, 3, width, height)
     assert got.shape == (n_img, 21 * k) and np.array_equal(got, ref)
     assert np.array_equal(codes.ravel(), oracle.compute_vocab_features(vocab, feats))
+
+
+def test_hist_kms_file_to_file(backend, tmp_path):
+    # projected descriptors of 4 images x 50 keypoints + vocabulary -> the histogram file whose
+    # rows svm_model / predict slice as [label | features | video_id, timestamp]
+    # (vision/utils/bovw_functions.py:133-159)
+    feats = sift_like(200, d=32, n_modes=5, seed=7)
+    vocab = sift_like(9, d=32, n_modes=5, seed=8)
+    proj = str(tmp_path / "projected.xml")
+    voc = bovw_files.write_vocab_file(str(tmp_path / "vocab.xml"), vocab)
+    labels = np.array([1, -1, 1, -1], dtype=np.int32)
+    ids = np.array([[11, 1000], [11, 2000], [12, 500], [13, 0]], dtype=np.int32)
+    bovw_files._write_tags(proj, [("cols", 32), ("nDescriptors", 200), ("nImg", 4)],
+                           [("labels", labels), ("ids", ids)])
+    feats.astype(np.float32).tofile(proj + ".desc")
+    out = str(tmp_path / "hist.xml")
+    assert bovw_files.hist_kms("/unused/bin", voc, proj, out, backend=backend) == out
+    hist = bovw_files.load_first_opencv_matrix(out)
+    assert hist.shape == (4, 1 + 9 + 2) and hist.dtype == np.float32
+    assert np.array_equal(hist[:, 0], labels) and np.array_equal(hist[:, -2:], ids)
+    code = oracle.vq(feats, vocab)[0]
+    ref = oracle.build_histogram([code[i * 50:(i + 1) * 50] for i in range(4)], 9, "l1")
+    assert np.array_equal(hist[:, 1:-2], ref.astype(np.float32))
+    assert np.allclose(hist[:, 1:-2].sum(1), 1.0)
+    # ragged images through an offsets matrix, no labels: zeros in the label / id columns
+    bovw_files._write_tags(proj, [("cols", 32), ("nDescriptors", 200)],
+                           [("imageOffsets", np.array([0, 0, 120, 200], dtype=np.int32))])
+    if backend.name.startswith("hip"):
+        assert bovw_files.main(["hist_kms", voc, proj, out]) == 0        # the binary's argv
+    else:
+        bovw_files.hist_kms(None, voc, proj, out, backend=backend)
+    hist = bovw_files.load_first_opencv_matrix(out)
+    assert hist.shape == (3, 12) and not hist[0].any() and not hist[:, [0, -2, -1]].any()
+    ref = oracle.build_histogram([code[:0], code[:120], code[120:]], 9, "l1")
+    assert np.array_equal(hist[:, 1:-2], ref.astype(np.float32))
+    with pytest.raises(IOError):
+        bovw_files.hist_kms(None, voc, str(tmp_path / "missing.xml"), out, backend=backend)
+    bovw_files._write_tags(proj, [("cols", 32), ("nDescriptors", 200), ("nImg", 3)])
+    with pytest.raises(IOError):
+        bovw_files.hist_kms(None, voc, proj, out, backend=backend)       # 200 rows, 3 images

@@ -236,9 +236,10 @@ def test_knn_scikit_histogram_space(backend, metric):
     assert knn.test_probability(g["q"], 0.4) == ref
 
 
-def test_knn_scikit_intersection_metric_and_knn_trainer(backend):
+def test_knn_scikit_intersection_metric_and_shortlist_index(backend, tmp_path):
     from image_classification_amd.clustering import intersection
-    from image_classification_amd.knn_training import KnnTrainer
+    from image_classification_amd.shortlist import (fit_shortlist_index, load_shortlist_index,
+                                                        save_shortlist_index)
     g = load("g8_hist_knn")
     knn = KNNScikit(3, metric=intersection, weights="distance", algorithm="auto", backend=backend)
     knn.train(g["fit_x"], list(g["labels"]))
@@ -246,21 +247,24 @@ def test_knn_scikit_intersection_metric_and_knn_trainer(backend):
     assert np.array_equal(ind, g["intersection_ind"])
     assert oracle.check_close(dist, g["intersection_dist"], abs_floor=1e-6) <= REL
 
-    class Logo(object):
-        def __init__(self, n, label):
-            self.path, self.target_label_id = "logo%d.jpg" % n, label
-
     class Bow(object):   # stands for BagOfWords.extract over image files
         def extract(self, paths):
             rows = [int(p[4:-4]) for p in paths]
             return ["desc%d" % r for r in rows], g["fit_x"][rows]
 
-    trainer = KnnTrainer(Bow(), backend=backend)
-    trainer.train([Logo(n, int(l)) for n, l in enumerate(g["labels"])])
-    assert trainer.logos[5].image_desc == "desc5" and np.array_equal(trainer.logos[5].feature,
-                                                                     g["fit_x"][5])
-    ind2 = trainer._knnsck.get_neighbors(g["q"], 3, dist=False)
-    assert np.array_equal(ind2, g["intersection_ind"])
+    paths = ["logo%d.jpg" % n for n in range(len(g["labels"]))]
+    index, descs, hists = fit_shortlist_index(Bow(), paths, [int(l) for l in g["labels"]],
+                                              backend=backend)
+    assert descs[5] == "desc5" and np.array_equal(hists[5], g["fit_x"][5])
+    assert np.array_equal(index.get_neighbors(g["q"], 3, dist=False), g["intersection_ind"])
+    with pytest.raises(ValueError):
+        fit_shortlist_index(Bow(), paths, [1, 2], backend=backend)
+    # on disk: rows, labels, metric by name -- no pickle
+    save_shortlist_index(index, str(tmp_path / "knn"))
+    again = load_shortlist_index(str(tmp_path / "knn"), backend=backend)
+    assert again.metric is intersection and again.n_neighbors == 3
+    assert np.array_equal(again.get_neighbors(g["q"], 3, dist=False), g["intersection_ind"])
+    assert list(again.test(g["q"])) == list(index.test(g["q"]))
 
 
 def _desc(d):
@@ -588,3 +592,52 @@ def test_codebook_edited_in_place_between_calls_is_seen():
     code1, dist1 = vq(obs, cb)
     assert code1[0] == target and dist1[0] == 0.0
     assert np.array_equal(code1[1:], code0[1:]) or np.mean(code1[1:] == code0[1:]) > 0.99
+
+
+class _SavableExtractor(object):
+    """A feature extractor with the save_to_file / load_from_file pair model directories rely on."""
+    def __init__(self, scale=1.0):
+        self.scale = scale
+
+    def extract(self, image_list):
+        out = []
+        for seed in image_list:
+            from image_classification_amd.synthetic import sift_like
+            d = sift_like(30, n_modes=4, seed=int(seed)) * np.float32(self.scale)
+            out.append(([(float(i), 0.0) for i in range(30)], d))
+        return out
+
+    def save_to_file(self, path):
+        with open(path, "w") as f:
+            f.write(repr(self.scale))
+
+    @classmethod
+    def load_from_file(cls, path):
+        with open(path) as f:
+            return cls(float(f.read()))
+
+
+def test_bag_of_words_model_directory_round_trip(backend, tmp_path):
+    from image_classification_amd import SpatialBagOfWords
+    from image_classification_amd.synthetic import sift_like
+    vocab = sift_like(12, n_modes=4, seed=5).astype(np.float64)
+    bow = BagOfWords(_SavableExtractor(1.0), vocab=vocab, norm="l2", backend=backend)
+    d = str(tmp_path / "bow")
+    bow.save_to_dir(d)
+    assert sorted(os.listdir(d)) == ["bow.json", "feat_ext", "vocab.npy"]
+    back = BagOfWords.load_from_dir(d, backend=backend)
+    assert isinstance(back.feat_ext, _SavableExtractor) and back.norm == "l2"
+    assert np.array_equal(back.vocab, vocab) and back.vocabsize == 12
+    assert np.array_equal(back.extract([1, 2])[1], bow.extract([1, 2])[1])
+    # a directory that holds only the reference's vocab.npy: the caller supplies the extractor
+    os.unlink(os.path.join(d, "bow.json"))
+    with pytest.raises(ValueError):
+        BagOfWords.load_from_dir(d, backend=backend)
+    legacy = BagOfWords.load_from_dir(d, feat_ext=_SavableExtractor(1.0), backend=backend)
+    assert legacy.norm == "l1" and np.array_equal(legacy.vocab, vocab)
+    # subclass parameters travel in the manifest
+    sbow = SpatialBagOfWords(2, 40, 60, _SavableExtractor(), vocab=vocab, backend=backend)
+    sbow.save_to_dir(str(tmp_path / "sbow"))
+    sback = SpatialBagOfWords.load_from_dir(str(tmp_path / "sbow"), backend=backend)
+    assert (sback.n_levels, sback.im_height, sback.im_width) == (2, 40, 60)
+    assert isinstance(sback, SpatialBagOfWords)
