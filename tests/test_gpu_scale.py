@@ -40,15 +40,22 @@ def test_config3_logo_search_both_directions():
     bounds = list(range(0, ndb + 1, 250_000))
     recs = torch.stack([ops.assign_top2_rec(q, db[lo:hi]) for lo, hi in zip(bounds[:-1], bounds[1:])])
     merged = ops.top2_merge(recs.contiguous(), bounds[:-1], 0.8)
+    # every shard's pair is exact, so the merge can differ from the unsharded search only where two
+    # different squared distances round to the same float32 square root (measured: no row)
     same = (merged[0] == full[0].long()) & (merged[2] == full[2].long())
-    assert same.float().mean() > 0.999
+    assert same.float().mean() >= 0.9995
     assert torch.equal(merged[1][same], full[1][same])
-    # bounded sample against the float64 oracle (queries vs the first 200k database rows)
+    # bounded sample against the float64 oracle (queries vs the first 200k database rows):
+    # measured agreement 1.0 for both neighbours; one row of 500 is the margin
     rd, ri = oracle.topk(q[:500].cpu().numpy(), db[:200_000].cpu().numpy(), 3)
     got = ops.assign_top2(q[:500], db[:200_000], 0.8)
+    direct = ops.assign_top2_exact(q[:500], db[:200_000], 0.8)
     for col, rank in ((0, 0), (2, 1)):
         must, bad, agree = oracle.check_indices(got[col].cpu().numpy(), ri, rd, rank)
-        assert bad == 0 and agree > 0.995
+        print("config 3 transposed, neighbour %d: %d must-match rows, %d bad, agreement %.4f"
+              % (rank + 1, must, bad, agree))
+        assert bad == 0 and agree >= 0.998
+        assert torch.equal(got[col], direct[col])             # and the direct float32 search, exactly
 
 
 def test_config4_one_lloyd_iteration_share():
