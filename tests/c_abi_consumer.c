@@ -144,6 +144,40 @@ int main(void) {
         if (fabs(ref[j][t] - sums[j][t]) > 1e-9 * (fabs(ref[j][t]) + 1.0)) { ++bad; fprintf(stderr, "sums[%d][%d]\n", j, t); break; }
     }
   }
+  /* a caller that keeps a codebook: auxiliary block once, then searches that bring it along; and
+   * the entry point that allocates nothing -- both must repeat the answer above bit for bit */
+  {
+    float* daux;
+    int32_t* dj;
+    float* de;
+    static int32_t j1a[N], j1s[N];
+    static float e1a[N], e1s[N];
+    HIPCHECK(hipMalloc((void**)&daux, (size_t)ic_codebook_aux_floats(K) * 4));
+    HIPCHECK(hipMalloc((void**)&dj, N * 4));
+    HIPCHECK(hipMalloc((void**)&de, N * 4));
+    ICCHECK(ic_codebook_aux(h, dc, K, D, daux, s));
+    ICCHECK(ic_assign_top1(h, dx, N, dc, K, D, daux, dj, de, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipMemcpy(j1a, dj, sizeof j1a, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(e1a, de, sizeof e1a, hipMemcpyDeviceToHost));
+    ICCHECK(ic_assign_top1_static(h, dx, N, dc, K, D, daux, dj, de, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipMemcpy(j1s, dj, sizeof j1s, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(e1s, de, sizeof e1s, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i)
+      if (j1a[i] != i1[i] || j1s[i] != i1[i] || e1a[i] != d1[i] || e1s[i] != d1[i]) {
+        ++bad;
+        fprintf(stderr, "row %d: aux / static entry differs\n", i);
+        break;
+      }
+    if (ic_assign_top1_static(h, dx, (int64_t)1 << 24, dc, K, D, daux, dj, de, s) != IC_ELIMIT) {
+      ++bad;
+      fprintf(stderr, "static entry accepted 16M rows\n");
+    }
+    HIPCHECK(hipFree(daux));
+    HIPCHECK(hipFree(dj));
+    HIPCHECK(hipFree(de));
+  }
   /* error convention */
   if (ic_assign_top1(h, dx, N, dc, K, 200, NULL, di1, dd1, s) != IC_EINVAL) { ++bad; fprintf(stderr, "d=200 accepted\n"); }
   if (ic_hist(NULL, di1, doff, N_IMG, K, IC_NORM_L1, 0.5, dhist, s) != IC_EHANDLE) { ++bad; fprintf(stderr, "NULL handle accepted\n"); }
