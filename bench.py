@@ -372,8 +372,8 @@ def comm_records(torch, dist, fence, D, backend, dev, rank, world, use_dist, dis
     reps = 3
     for _ in range(reps):
         rec = timed("search_ms", lambda: backend.assign_top2_rec(q, index_cb))
-        gathered, bases = timed("allgather_ms", lambda: D.gather_records(rec, lo))
-        timed("merge_ms", lambda: backend.top2_merge(gathered, bases, 0.8))
+        gathered = timed("allgather_ms", lambda: D.gather_records(rec, lo))
+        timed("merge_ms", lambda: backend.top2_merge(gathered, None, 0.8))
     names = sorted(tot)
     vals = fence.max_over_ranks([tot[n] / reps for n in names])
     same = True

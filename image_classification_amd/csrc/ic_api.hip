@@ -506,7 +506,7 @@ int ic_top2_merge(void* handle, const ic_top2_rec* gathered, int n_shards, int64
   if (n < 0 || n_shards < 1 || n_shards > ic::kMaxShards)
     return fail(IC_EINVAL, "ic_top2_merge: need n >= 0 and 1 <= n_shards <= %d", ic::kMaxShards);
   if (n == 0) return IC_OK;
-  if (!gathered || !shard_base || !i1) return fail(IC_EINVAL, "ic_top2_merge: NULL pointer");
+  if (!gathered || !i1) return fail(IC_EINVAL, "ic_top2_merge: NULL pointer");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");

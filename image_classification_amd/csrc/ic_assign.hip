@@ -1256,8 +1256,10 @@ struct ShardBases {
   int64_t b[kMaxShards];
 };
 
+// packed != 0: every shard's block holds n + 1 records, the last one carrying the shard's base as
+// an int64 in its first eight bytes (what the ranks all-gather, so no base travels separately).
 __global__ __launch_bounds__(256) void k_top2_merge(const ic_top2_rec* __restrict__ g, int n_shards,
-                                                    int64_t n, ShardBases base,
+                                                    int64_t n, ShardBases base, int packed,
                                                     int64_t* __restrict__ i1o, float* __restrict__ d1o,
                                                     int64_t* __restrict__ i2o, float* __restrict__ d2o,
                                                     float ratio, uint8_t* __restrict__ mask) {
@@ -1278,9 +1280,11 @@ __global__ __launch_bounds__(256) void k_top2_merge(const ic_top2_rec* __restric
       d2 = d; i2 = i;
     }
   };
+  const int64_t stride = packed ? n + 1 : n;
   for (int s = 0; s < n_shards; ++s) {
-    const ic_top2_rec r = g[(int64_t)s * n + row];
-    const int64_t b = base.b[s];
+    const ic_top2_rec r = g[(int64_t)s * stride + row];
+    const int64_t b = packed ? *reinterpret_cast<const int64_t*>(&g[(int64_t)s * stride + n])
+                             : base.b[s];
     push(r.d1, r.i1 < 0 ? -1 : r.i1 + b);
     push(r.d2, r.i2 < 0 ? -1 : r.i2 + b);
   }
@@ -1298,9 +1302,10 @@ hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t 
   const int64_t grid = (n + 255) / 256;
   if (grid < 1) return hipSuccess;
   ShardBases sb;
-  for (int i = 0; i < kMaxShards; ++i) sb.b[i] = i < n_shards ? shard_base_host[i] : 0;
+  for (int i = 0; i < kMaxShards; ++i)
+    sb.b[i] = (shard_base_host && i < n_shards) ? shard_base_host[i] : 0;
   hipLaunchKernelGGL(k_top2_merge, dim3((unsigned)grid), dim3(256), 0, s, gathered, n_shards, n,
-                     sb, i1, d1, i2, d2, ratio, mask);
+                     sb, shard_base_host ? 0 : 1, i1, d1, i2, d2, ratio, mask);
   return hipGetLastError();
 }
 

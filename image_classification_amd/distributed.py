@@ -184,31 +184,48 @@ def kmeans_fit_sharded(x_local, init, iters, backend=None, group=None, on_empty=
                  on_empty=on_empty)
 
 
+_trailers = {}
+
+
+def pack_records(rec, index_base):
+    """[n, 4] records -> [n + 1, 4] whose trailing record carries the shard's base (an int64 in
+    its first two words): the block a rank contributes to the all-gather, so the bases need no
+    collective of their own and never come back to the host."""
+    key = (str(rec.device), int(index_base))
+    trailer = _trailers.get(key)
+    if trailer is None:
+        words = np.zeros(4, dtype=np.int32)
+        words[:2] = np.array([int(index_base)], dtype=np.int64).view(np.int32)
+        if len(_trailers) > 64:
+            _trailers.clear()
+        trailer = _trailers[key] = torch.from_numpy(words).to(rec.device)
+    out = torch.empty((rec.shape[0] + 1, 4), dtype=torch.int32, device=rec.device)
+    out[:-1] = rec
+    out[-1] = trailer
+    return out
+
+
 def gather_records(rec, index_base, group=None):
-    """All-gather every rank's per-row records [n, 4] (int32 words of ic_top2_rec) into
-    [n_ranks, n, 4], and the ranks' index bases into a list of ints."""
+    """All-gather every rank's packed records: int32 [n_ranks, n + 1, 4] (see pack_records)."""
     rank, n = world(group)
+    send = pack_records(rec, index_base)
     if n == 1:
-        return rec.unsqueeze(0).contiguous(), [int(index_base)]
-    rows = rec.shape[0]
-    flat = torch.empty((n * rows, rec.shape[1]), dtype=rec.dtype, device=rec.device)
-    _all_gather_into(flat, rec, group)                # rank r -> rows [r*rows, (r+1)*rows)
-    bases = torch.zeros(n, dtype=torch.int64, device=rec.device)
-    bases[rank] = int(index_base)
-    _all_reduce(bases, group)
-    return flat.view(n, rows, rec.shape[1]), [int(v) for v in bases.cpu()]
+        return send.unsqueeze(0)
+    flat = torch.empty((n * send.shape[0], 4), dtype=send.dtype, device=send.device)
+    _all_gather_into(flat, send, group)               # rank r -> rows [r*(n+1), (r+1)*(n+1))
+    return flat.view(n, send.shape[0], 4)
 
 
 def knn2_index_sharded(queries, index_local, index_base, ratio=0.8, backend=None, group=None):
     """Two nearest index rows of every query when the index is split over ranks.
 
     queries: replicated [n, d]; index_local: this rank's index rows; index_base: global row number
-    of its first row.  Returns (i1 int64, d1, i2 int64, d2, mask) identical on every rank.
+    of its first row.  Returns (i1 int64, d1, i2 int64, d2, mask) identical on every rank.  One
+    collective (the all-gather of 16 bytes per query and rank), no host round trip.
     """
     b = backend or default_backend()
     rec = b.assign_top2_rec(b.f32(queries), b.codebook(index_local))
-    gathered, bases = gather_records(rec, index_base, group)
-    return b.top2_merge(gathered, bases, ratio)
+    return b.top2_merge(gather_records(rec, index_base, group), None, ratio)
 
 
 def knn2_rows_sharded(index, rows_local, ratio=0.8, backend=None, gather=False, group=None):

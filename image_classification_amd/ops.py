@@ -427,16 +427,22 @@ def assign_top2_rec(x, c, c_aux=None):
 
 
 def top2_merge(gathered, shard_base, ratio=0.8, want_mask=True):
-    """gathered: [n_shards, n, 4] int32 (ic_top2_rec words); shard_base: sequence of ints."""
+    """gathered: [n_shards, n, 4] int32 (ic_top2_rec words); shard_base: sequence of ints -- or
+    None when gathered is [n_shards, n + 1, 4] and the last record of every shard carries its
+    base as an int64 (see `pack_records`)."""
     if gathered.dim() != 3 or gathered.shape[2] != 4 or gathered.dtype != torch.int32:
         raise ValueError("gathered must be int32 [n_shards, n, 4]")
     if not gathered.is_contiguous():
         raise ValueError("gathered must be contiguous")
     dev = _dev_index(gathered)
     n_shards, n = gathered.shape[0], gathered.shape[1]
-    if len(shard_base) != n_shards:
-        raise ValueError("need one shard base per shard")
-    base = (ctypes.c_int64 * n_shards)(*[int(b) for b in shard_base])
+    if shard_base is None:
+        n -= 1
+        base = None
+    else:
+        if len(shard_base) != n_shards:
+            raise ValueError("need one shard base per shard")
+        base = (ctypes.c_int64 * n_shards)(*[int(b) for b in shard_base])
     i1 = torch.empty(n, dtype=torch.int64, device=gathered.device)
     i2 = torch.empty(n, dtype=torch.int64, device=gathered.device)
     d1 = torch.empty(n, dtype=torch.float32, device=gathered.device)

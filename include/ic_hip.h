@@ -152,7 +152,11 @@ int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, 
                        const float* c_aux, ic_top2_rec* rec, void* stream);
 
 /* Merge per-shard top-2 records: gathered [n_shards][n] records; shard_base (HOST pointer,
- * n_shards int64) is added to each shard's local indices.  Order is (distance, global index).
+ * n_shards int64) is added to each shard's local indices.  With shard_base == NULL the bases
+ * travel inside the data instead: gathered is [n_shards][n + 1] records and the last record of a
+ * shard's block holds its base as an int64 in its first eight bytes -- what ranks exchange in one
+ * all-gather, so that nothing has to come back to the host before the merge.
+ * Order is (distance, global index).
  * Outputs as ic_assign_top2 but with int64 indices (sklearn returns int64,
  * model/classifiers.py:196).  i2/d2/mask may be NULL. */
 int ic_top2_merge(void* handle, const ic_top2_rec* gathered, int n_shards, int64_t n,

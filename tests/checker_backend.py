@@ -88,6 +88,10 @@ class CheckerBackend(object):
 
     def top2_merge(self, gathered, shard_base, ratio=0.8):
         g = gathered.numpy()
+        if shard_base is None:       # bases packed into a trailing record per shard
+            shard_base = [int(np.ascontiguousarray(g[s, -1, :2]).view(np.int64)[0])
+                          for s in range(g.shape[0])]
+            g = g[:, :-1]
         shards = []
         for s in range(g.shape[0]):
             d = np.stack([g[s, :, 0].copy().view(np.float32), g[s, :, 2].copy().view(np.float32)], 1)

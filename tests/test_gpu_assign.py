@@ -259,6 +259,13 @@ def test_merge_of_index_shards_equals_unsharded():
     recs = [ops.assign_top2_rec(xd, _dev(c[lo:hi])) for lo, hi in zip(bounds[:-1], bounds[1:])]
     gathered = torch.stack(recs).contiguous()
     mi1, md1, mi2, md2, mmask = ops.top2_merge(gathered, bounds[:-1], 0.8)
+    # the same with every shard's base packed behind its records (what the ranks all-gather)
+    from image_classification_amd.distributed import pack_records
+    packed = torch.stack([pack_records(r, b) for r, b in zip(recs, bounds[:-1])]).contiguous()
+    for a, b in zip(ops.top2_merge(packed, None, 0.8), (mi1, md1, mi2, md2, mmask)):
+        assert torch.equal(a, b)
+    big = pack_records(recs[0][:3], (1 << 40) + 5)           # bases beyond 32 bits survive
+    assert int(ops.top2_merge(big.unsqueeze(0).contiguous(), None, 0.8)[0][0]) >= (1 << 40)
     i1, d1, i2, d2, mask = ops.assign_top2(xd, _dev(c), 0.8)
     rd, ri = oracle.topk(x, c, 3)
     for got, rank in ((mi1, 0), (mi2, 1)):
