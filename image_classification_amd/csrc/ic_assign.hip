@@ -377,11 +377,14 @@ __device__ __forceinline__ void tile_epilogue_all(const f32x16 (&acc)[XT], Top2 
   }
 }
 
-// Slot of row r's record from K-split sp.  Split 0 of every row comes first ([N] records); only
-// the rows from split_row0 on (the last, partly filled round of row tiles) have further splits,
-// stored behind as [nsplit - 1][N - split_row0].
-__device__ __forceinline__ int64_t part_slot(int sp, int64_t r, int64_t N, int64_t split_row0) {
-  return sp == 0 ? r : N + (int64_t)(sp - 1) * (N - split_row0) + (r - split_row0);
+// Slot of row r's record in list l = 2 * (K-split) + (lane half).  The two lanes that hold a
+// descriptor rank disjoint halves of every tile's codewords and each writes its own record: kept
+// apart, the halves are two more places where k_rescore can find the INDEX of a candidate inside
+// the error band, which quarters the rows that need the second look.  Lists 0 and 1 exist for
+// every row ([2][N] records); only the rows from split_row0 on (the last, partly filled round of
+// row tiles) have further lists, stored behind as [2 nsplit - 2][N - split_row0].
+__device__ __forceinline__ int64_t part_slot(int l, int64_t r, int64_t N, int64_t split_row0) {
+  return l < 2 ? (int64_t)l * N + r : 2 * N + (int64_t)(l - 2) * (N - split_row0) + (r - split_row0);
 }
 
 // aux: the codebook's auxiliary block (see AuxLayout in ic_internal.h): mean vector, the two
@@ -511,31 +514,22 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     }
   }
 
-  // decode (tile, register) -> codeword index, fold the two lane halves, store
+  // decode (tile, register) -> codeword index and store this lane's list
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt) {
-    Top2 b = best[xt];
+    const Top2& b = best[xt];
     auto decode = [h](int enc) {
       if (enc < 0) return -1;
       const int t = enc >> 4, r = enc & 15;
       return t * kTileK + 8 * (r >> 2) + 4 * h + (r & 3);
     };
-    b.i1 = decode(b.i1);
-    b.i2 = decode(b.i2);
-    const float od1 = __shfl_xor(b.d1, 32);
-    const float od2 = __shfl_xor(b.d2, 32);
-    const float od3 = __shfl_xor(b.d3, 32);
-    const int oi1 = __shfl_xor(b.i1, 32);
-    const int oi2 = __shfl_xor(b.i2, 32);
-    const float t3 = third_of_union(b.d1, b.d2, b.d3, od1, od2, od3);
-    top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, od1, oi1, od2, oi2);
     const int64_t r = row0 + xt * 32 + j;
-    if (h == 0 && r < N) {
+    if (r < N) {
       ic_top2_rec rec;
-      rec.d1 = b.d1; rec.i1 = b.i1; rec.d2 = b.d2; rec.i2 = b.i2;
-      const int64_t slot = part_slot(sp, r, N, (int64_t)full_tiles * (XT * NW * 32));
+      rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
+      const int64_t slot = part_slot(2 * sp + h, r, N, (int64_t)full_tiles * (XT * NW * 32));
       part[slot] = rec;
-      part3[slot] = t3;
+      part3[slot] = b.d3;
     }
   }
 }
@@ -593,7 +587,7 @@ hipError_t assign_init() {
 int64_t assign_part_records(const AssignPlan& p, int64_t n) {
   int64_t split_row0 = p.full_tiles * (int64_t)p.rows_per_wg;
   if (split_row0 > n) split_row0 = n;
-  return n + (int64_t)(p.nsplit - 1) * (n - split_row0);
+  return 2 * n + (int64_t)(2 * p.nsplit - 2) * (n - split_row0);   // see part_slot
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
@@ -711,8 +705,9 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   for (int64_t row = row_begin + grp; row < row_end; row += 16) {
     ic_top2_rec b = part[row];
     float v3 = part3[row];
-    const int ns = row >= split_row0 ? nsplit : 1;   // rows below split_row0 were not split
-    // v3: third smallest value over all splits; u3: the smallest "third of one split", i.e. the
+    // lists of this row: the two lane halves of every K-split (rows below split_row0 were not split)
+    const int ns = row >= split_row0 ? 2 * nsplit : 2;
+    // v3: third smallest value over all lists; u3: the smallest "third of one list", i.e. the
     // best candidate whose INDEX no record holds
     float u3 = v3;
     for (int s = 1; s < ns; ++s) {
@@ -748,9 +743,9 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       const int ti = a1; a1 = a2; a2 = ti;
     }
     bool unsure = (v3 - ref) <= band;   // false on NaN / inf - inf
-    if (unsure && ns > 1 && !((u3 - ref) <= band)) {
-      // every candidate inside the band sits in the record of some split, index and all (no
-      // split has a third one there): evaluate them directly too and keep the two best of
+    if (unsure && !((u3 - ref) <= band)) {
+      // every candidate inside the band sits in the record of some list, index and all (no
+      // list has a third one there): evaluate them directly too and keep the two best of
       // everything evaluated
       for (int s = 0; s < ns; ++s) {
         const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];

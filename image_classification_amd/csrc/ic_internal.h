@@ -26,8 +26,8 @@ struct AssignPlan {
   int nsplit, split_base, split_extra;
 };
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p);
-// records the partial buffer of a plan holds: one per row, plus nsplit - 1 more for every row of
-// the K-split tail
+// records the partial buffer of a plan holds: two per row (one per lane half), plus
+// 2 nsplit - 2 more for every row of the K-split tail
 int64_t assign_part_records(const AssignPlan& p, int64_t n);
 // once per device, with that device current: function attributes of the search kernels
 hipError_t assign_init();

@@ -113,9 +113,9 @@ int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int6
  * static device array of IC_STATIC_SCRATCH_BYTES instead of the handle's growable workspace, and
  * the call consists of kernel launches on `stream` only: no hipMalloc / hipFree, no event, no
  * synchronisation.  Inputs that need more scratch are rejected with IC_ELIMIT before anything is
- * launched (16 bytes per row, plus 16 more per K-split for the rows of the last partly filled
- * round of workgroups, plus 4 bytes per codeword: 1M rows x 10k codewords fits, about 4M rows is
- * the ceiling).  All calls on one GPU share that array -- from every handle and every stream --
+ * launched (about 50 bytes per row, more for the rows of the last partly filled round of
+ * workgroups, plus 4 bytes per codeword: 1M rows x 10k codewords fits, about 1.3M rows is the
+ * ceiling).  All calls on one GPU share that array -- from every handle and every stream --
  * so two calls that overlap in time on one GPU race; order them on one stream or with events. */
 int ic_assign_top1_static(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                           const float* c_aux, int32_t* idx, float* dist, void* stream);
