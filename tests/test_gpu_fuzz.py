@@ -30,13 +30,17 @@ def test_search_hist_centroid_over_random_shapes():
         tag = "trial %d: n=%d k=%d d=%d" % (trial, n, k, d)
         i1, d1, i2, d2, mask = (t.cpu().numpy() for t in ops.assign_top2(_dev(x), _dev(c), 0.8))
         rd, ri = oracle.topk(x, c, min(3, k))
-        # low-dimensional rows sit closer to their neighbours than float32 resolves from the
-        # norms; such rows may pick a neighbour inside that resolution (see the helper)
-        assert oracle.mismatches_outside_f32_band(i1, x, c, ri, rd, 0) == 0, tag
+        # the strict rule, also for low-dimensional rows that sit far closer to their neighbours
+        # than their own norm: such rows are decided by direct differences
+        must, bad, _ = oracle.check_indices(i1, ri, rd, 0) if k >= 2 else (0, int((i1 != 0).sum()), 1)
+        assert bad == 0, tag
         ok = i1 == ri[:, 0]
         assert oracle.check_close(d1[ok], rd[ok, 0], abs_floor=1e-6 * scale) <= 1e-4, tag
-        if k >= 2:
-            assert oracle.mismatches_outside_f32_band(i2, x, c, ri, rd, 1) == 0, tag
+        if k >= 3:
+            must, bad, _ = oracle.check_indices(i2, ri, rd, 1)
+            assert bad == 0, tag
+        elif k == 2:
+            assert set(map(tuple, np.sort(np.stack([i1, i2], 1), 1))) == {(0, 1)}, tag
         else:
             assert (i2 == -1).all() and np.isinf(d2).all(), tag
         # histogram of the codes over ragged images (some empty), bit-exact

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised comparison of the MFMA search with the direct float32 search, both on the device:
 soak.py [cases] [seed].  Shapes cover both workgroup geometries, K-splits, padded dimensions,
-exact ties and duplicated codewords; indices must agree wherever the direct search's gap between
-the candidates exceeds the float32 resolution of the norm expansion, hinted and unhinted searches
-must be identical, and the record / merge path must equal the single search."""
+exact ties, duplicated codewords and data far from the origin; indices, distances and the ratio
+mask must EQUAL the direct search's on every row, hinted and unhinted searches must be identical,
+and the record / merge path must equal the single search."""
 import os
 import sys
 
@@ -20,7 +20,6 @@ def main():
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     rng = np.random.default_rng(seed)
-    worst = 0.0
     for case in range(cases):
         n = int(rng.choice([1, 31, 64, 513, 4096, 20000, 140000])) + int(rng.integers(0, 300))
         k = int(rng.choice([1, 2, 33, 200, 1000, 2047, 2048, 2100, 5000, 9000])) + int(rng.integers(0, 50))
@@ -39,28 +38,22 @@ def main():
                 c[k // 2] = c[0]
                 c[k - 1] = c[1]
             x[: min(n, k)] = c[: min(n, k)]
+        if case % 4 == 3:  # the same rows far from the origin: norms dwarf the distances
+            shift = float(rng.choice([50.0, 1000.0]))
+            x = x + shift
+            c = c + shift
         i1, d1, i2, d2, m = ops.assign_top2(x, c, 0.8)
         e1, ed1, e2, ed2, em = ops.assign_top2_exact(x, c, 0.8)
-        # resolution of the expansion in squared distance, as a distance gap at this row
-        xn = (x * x).sum(1).sqrt()
-        cn = (c * c).sum(1).sqrt().max()
-        band_sq = 3 * 7.7e-6 * (cn * cn + 2 * xn * cn) + 1e-30
         tag = "case %d: n=%d k=%d d=%d kind=%d" % (case, n, k, d, kind)
-        # best: every candidate the direct search ranks below must be clearly worse, else free
-        if k >= 2:
-            clear1 = (ed2 * ed2 - ed1 * ed1) > band_sq
-        else:
-            clear1 = torch.ones_like(ed1, dtype=torch.bool)
-        bad1 = int(((i1 != e1) & clear1).sum())
-        assert bad1 == 0, tag + ": %d best neighbours differ outside the float32 band" % bad1
-        same1 = i1 == e1
-        # the two kernels add the 128 squared differences in different orders
-        assert torch.allclose(d1[same1], ed1[same1], rtol=2e-6, atol=1e-6), \
-            tag + ": distances of equal winners differ"
-        if kind == 1 and d == 128:
-            assert torch.equal(i1, e1) and torch.equal(i2, e2), tag + ": exact data must agree exactly"
-        agree = float(same1.float().mean())
-        worst = max(worst, 1 - agree)
+        for name, a, b in (("i1", i1, e1), ("i2", i2, e2), ("mask", m, em)):
+            bad = int((a != b).sum())
+            assert bad == 0, tag + ": %s differs from the direct search on %d rows" % (name, bad)
+        for name, a, b in (("d1", d1, ed1), ("d2", d2, ed2)):
+            bad = int((a.view(torch.int32) != b.view(torch.int32)).sum())
+            assert bad == 0, tag + ": %s differs in bits on %d rows" % (name, bad)
+        t1, td1 = ops.assign_top1(x, c)
+        assert torch.equal(t1, e1) and torch.equal(td1.view(torch.int32), ed1.view(torch.int32)), \
+            tag + ": top-1 search differs from the direct search"
         # hinted search: identical to the unhinted one, whatever the hint
         hint = e1.clone()
         hint[::3] = torch.randint(0, k, (hint[::3].numel(),), device="cuda", generator=g).int()
@@ -73,11 +66,12 @@ def main():
             recs = torch.stack([ops.assign_top2_rec(x, c[:cut].contiguous()),
                                 ops.assign_top2_rec(x, c[cut:].contiguous())]).contiguous()
             m1, md1, m2, md2, mm = ops.top2_merge(recs, [0, cut], 0.8)
-            ok = (m1 == i1.long())
-            assert int((~ok & clear1).sum()) == 0, tag + ": merged shards differ"
+            # shards are merged by Euclidean distance: equal unless two different squared
+            # distances round to the same square root
+            differ = (m1 != i1.long()) & (md1 != d1)
+            assert int(differ.sum()) == 0, tag + ": merged shards differ"
         if case % 20 == 19:
-            print("%d cases ok, largest disagreement with the direct search inside the band %.2e"
-                  % (case + 1, worst), flush=True)
+            print("%d cases ok" % (case + 1), flush=True)
     torch.cuda.synchronize()
     print("SOAK_OK %d cases" % cases)
 
