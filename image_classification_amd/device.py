@@ -6,10 +6,13 @@ the kernels read stays in HBM between calls; it is looked up by a hash of the ho
 contents, so an array that was edited in place (or freed and reallocated at the same address)
 never finds a stale copy.  Hashing costs about as much as reading the array once (xxh3: ~0.1 ms
 per MB), a fraction of the conversion + upload + auxiliary block it saves; a caller that wants
-not even that passes a `ResidentCodebook` it built once.
+not even that freezes its vocabulary (`vocab.setflags(write=False)`: a read-only array that is
+still the same object is recognised without reading it) or passes a `ResidentCodebook` it built
+once.
 """
 import os
 import threading
+import weakref
 import zlib
 
 import numpy as np
@@ -70,7 +73,18 @@ def _fingerprint(a):
     return (a.__array_interface__["data"][0], a.shape, a.dtype.str, digest)
 
 
+def _frozen(a):
+    """True when nothing can change the array's contents through numpy: it is read-only, and so
+    is every array it is a view of (a read-only view of a writable base can still change)."""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None or isinstance(a, (bytes, str))
+
+
 _cache = {}
+_frozen_hits = {}      # id(array) -> (weak reference to that very array, ResidentCodebook)
 _cache_lock = threading.Lock()
 _CACHE_MAX = 8
 
@@ -86,22 +100,38 @@ def resident(codebook, device=None):
     a = np.asarray(codebook)
     if a.ndim != 2:
         raise ValueError("codebook must be 2-D, got shape %s" % (a.shape,))
+    # A frozen array (`vocab.setflags(write=False)`) that is still the same Python object cannot
+    # have changed: it is recognised without reading a byte -- per-image calls as the reference
+    # issues them then cost no hash at all.
+    fkey = (os.getpid(), str(device), id(a))
+    if _frozen(a):
+        with _cache_lock:
+            entry = _frozen_hits.get(fkey)
+        if entry is not None and entry[0]() is a:
+            return entry[1]
     key = (os.getpid(), str(device)) + _fingerprint(a)
     with _cache_lock:
         hit = _cache.get(key)
-    if hit is not None:
-        return hit
-    rc = ResidentCodebook(a, device)
-    with _cache_lock:
-        if len(_cache) >= _CACHE_MAX:
-            _cache.pop(next(iter(_cache)))
-        _cache[key] = rc
-    return rc
+    if hit is None:
+        hit = ResidentCodebook(a, device)
+        with _cache_lock:
+            if len(_cache) >= _CACHE_MAX:
+                _cache.pop(next(iter(_cache)))
+            _cache[key] = hit
+    if _frozen(a):
+        with _cache_lock:
+            for k in [k for k, v in _frozen_hits.items() if v[0]() is None]:
+                _frozen_hits.pop(k)               # arrays that are gone
+            if len(_frozen_hits) >= 4 * _CACHE_MAX:
+                _frozen_hits.clear()
+            _frozen_hits[fkey] = (weakref.ref(a), hit)
+    return hit
 
 
 def forget(codebook=None):
     """Drop cached device copies (all of them, or the one of this array)."""
     with _cache_lock:
+        _frozen_hits.clear()
         if codebook is None:
             _cache.clear()
             return

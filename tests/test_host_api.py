@@ -576,6 +576,15 @@ def test_codebook_fingerprint_sees_every_element():
     assert _fingerprint(cb) == base
     view = cb[::2]                                             # non-contiguous arrays hash too
     assert _fingerprint(view) == _fingerprint(view) != base
+    # only an array nothing can write through is trusted without hashing
+    from image_classification_amd.device import _frozen
+    assert not _frozen(cb) and not _frozen(view)
+    ro_view = cb[:10]
+    ro_view.setflags(write=False)
+    assert not _frozen(ro_view)                                # its base is still writable
+    own = cb.copy()
+    own.setflags(write=False)
+    assert _frozen(own) and _frozen(own[::2])
 
 
 @pytest.mark.gpu
@@ -592,6 +601,19 @@ def test_codebook_edited_in_place_between_calls_is_seen():
     code1, dist1 = vq(obs, cb)
     assert code1[0] == target and dist1[0] == 0.0
     assert np.array_equal(code1[1:], code0[1:]) or np.mean(code1[1:] == code0[1:]) > 0.99
+    # a frozen vocabulary is recognised without hashing; thawed and edited, it is hashed again
+    from image_classification_amd import device
+    cb.setflags(write=False)
+    code2, _ = vq(obs, cb)
+    assert np.array_equal(code2, code1)
+    hits = dict(device._frozen_hits)
+    assert any(v[0]() is cb for v in hits.values())
+    code3, _ = vq(obs, cb)
+    assert np.array_equal(code3, code1)
+    cb.setflags(write=True)
+    cb[target] = 0.0
+    code4, _ = vq(obs, cb)
+    assert code4[0] != target
 
 
 class _SavableExtractor(object):
