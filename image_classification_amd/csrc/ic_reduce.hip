@@ -23,7 +23,7 @@ namespace ic {
 // counts do not depend on which lane wins.
 constexpr int kHistThreads = 256;
 constexpr int kTagSlots = 1024;      // tag slots per wave
-constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB + 16 KiB of tags in LDS
+constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB + 4 KiB of tags in LDS
 
 __device__ __forceinline__ double block_sum(double v, double* red /*[kHistThreads/64]*/) {
 #pragma unroll
@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
   const unsigned nb = (unsigned)nb64;
   volatile unsigned* hist = hsm;
   const int wave = tid >> 6, lane = tid & 63;
-  volatile unsigned* tags = hsm + bins_per_wg + wave * kTagSlots;
+  // a tag is a lane number: one byte each keeps the workgroup's LDS small (three workgroups of a
+  // 10 000-bin row per CU instead of two)
+  volatile unsigned char* tags = reinterpret_cast<volatile unsigned char*>(hsm + bins_per_wg) + wave * kTagSlots;
 
   for (unsigned b = tid; b < nb; b += kHistThreads) hist[b] = 0;
   const int64_t beg = offsets[img], end = offsets[img + 1];
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
       while ((left = __builtin_amdgcn_ballot_w64(pending)) != 0) {
         if (rounds < 2) {
           ++rounds;
-          if (pending) tags[slot] = (unsigned)lane;
-          if (pending && tags[slot] == (unsigned)lane) {
+          if (pending) tags[slot] = (unsigned char)lane;
+          if (pending && tags[slot] == (unsigned char)lane) {
             hist[code] = hist[code] + 1u;
             pending = false;
           }
@@ -131,20 +133,49 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
     for (unsigned b = tid; b < nb; b += kHistThreads) orow[b] = (double)hist[b];
     return;
   }
+  // Row reductions over the COUNTS (small integers, exact in float64 in any order): the sum of
+  // the transformed counts and of their squares.  Most bins of a bag-of-words row are empty, so
+  // the transform (a square root or a power) is only taken where a count is not zero.
   double s = 0.0, s2 = 0.0;
   if (norm_mode != IC_NORM_NONE) {
     for (unsigned b = tid; b < nb; b += kHistThreads) {
-      const double y = hist_transform((double)hist[b], norm_mode, power);
-      s += y;
-      s2 += y * y;
+      const unsigned cnt = hist[b];
+      if (cnt != 0) {
+        const double y = hist_transform((double)cnt, norm_mode, power);
+        s += y;
+        s2 += y * y;
+      }
     }
     s = block_sum(s, red);
     s2 = block_sum(s2, red);
   }
   const double f = hist_scale(norm_mode, s, s2);
-  for (unsigned b = tid; b < nb; b += kHistThreads) {
-    const double y = hist_transform((double)hist[b], norm_mode, power);
-    orow[b] = norm_mode == IC_NORM_L1 ? y * f : (norm_mode == IC_NORM_NONE ? y : y / f);
+  // two bins per lane and store (16 bytes) when the row allows it
+  const bool pair_ok = ((reinterpret_cast<uintptr_t>(orow) & 15) == 0);
+  const unsigned nb2 = pair_ok ? (nb & ~1u) : 0u;
+  for (unsigned b = 2 * tid; b < nb2; b += 2 * kHistThreads) {
+    double y[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned cnt = hist[b + e];
+      y[e] = 0.0;
+      if (cnt != 0) {
+        const double t = hist_transform((double)cnt, norm_mode, power);
+        y[e] = norm_mode == IC_NORM_L1 ? t * f : (norm_mode == IC_NORM_NONE ? t : t / f);
+      }
+    }
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 v = {y[0], y[1]};
+    *reinterpret_cast<f64x2*>(orow + b) = v;
+  }
+  for (unsigned b = nb2 + tid; b < nb; b += kHistThreads) {
+    const unsigned cnt = hist[b];
+    double y = 0.0;
+    if (cnt != 0) {
+      const double t = hist_transform((double)cnt, norm_mode, power);
+      y = norm_mode == IC_NORM_L1 ? t * f : (norm_mode == IC_NORM_NONE ? t : t / f);
+    }
+    orow[b] = y;
   }
 }
 
@@ -174,7 +205,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_normalise(int64_t k, int 
 hipError_t reduce_init() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist),
                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (kHistMaxBins + (kHistThreads / 64) * kTagSlots) * 4);
+                             kHistMaxBins * 4 + (kHistThreads / 64) * kTagSlots);
 }
 
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
@@ -184,7 +215,7 @@ hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_i
   const int bins_per_wg = k < kHistMaxBins ? (int)k : kHistMaxBins;
   const int64_t n_ranges = (k + bins_per_wg - 1) / bins_per_wg;
   if (n_img > 0x7fffffffLL || n_ranges > 65535) return hipErrorInvalidValue;
-  const int lds = (bins_per_wg + (kHistThreads / 64) * kTagSlots) * 4;   // see reduce_init()
+  const int lds = bins_per_wg * 4 + (kHistThreads / 64) * kTagSlots;   // see reduce_init()
   const int fused = n_ranges == 1 ? 1 : 0;
   hipLaunchKernelGGL(k_hist, dim3((unsigned)n_img, (unsigned)n_ranges), dim3(kHistThreads), lds, s,
                      codes, offsets, k, bins_per_wg, norm_mode, power, fused, cell_w, cell_k, out);
