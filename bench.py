@@ -164,6 +164,17 @@ def cpu_baseline(x_sample, codebook32, per_image, norm):
     n = x_sample.shape[0]
     n_img = n // per_image
     images = [x_sample[i * per_image:(i + 1) * per_image] for i in range(n_img)]
+    if ref.versions()["scipy"] is None:
+        # no scipy on this host: the float64 numpy restatement is all there is to time
+        t0 = time.perf_counter()
+        code, _ = oracle.vq(x_sample, codebook32)
+        oracle.build_histogram([code[i * per_image:(i + 1) * per_image] for i in range(n_img)],
+                               codebook32.shape[0], norm)
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "assignments/s", "cores": int(blas_threads),
+                "kind": "port", "host_cpus": os.cpu_count(), "libraries": ref.versions(),
+                "sample": "%d rows of the workload: float64 numpy restatement of vq + "
+                          "np.histogram (scipy is not installed here), %.1f s" % (n, dt)}, code
     t0 = time.perf_counter()
     codes, _h = ref.bow_quantize(images, vocab64, norm)
     dt = time.perf_counter() - t0
@@ -551,6 +562,8 @@ def run_rank(args):
         def step():
             return D.knn2_index_sharded(q, index_cb, lo, 0.8, backend=backend)
 
+    if args.steps < 1:
+        raise SystemExit("bench.py: --steps must be at least 1")
     for _ in range(args.warmup):
         step()
     fence()

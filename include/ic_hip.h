@@ -92,7 +92,7 @@ int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, 
 /* Test hook, no counterpart in the reference: after every following ic_assign_* call on this
  * handle the number of rows that took the second, direct look is copied (on the call's stream) to
  * the device word `count`; NULL switches it off. */
-int ic_debug_flagged(void* handle, uint32_t* count);
+int ic_debug_flagged(void* handle, uint32_t* count); /* `count` must stay valid until reset */
 
 /* Nearest codeword per row: idx[i] = argmin_j ||x_i - c_j|| (lowest j on ties), dist[i] = that
  * Euclidean distance.  Replaces scipy.cluster.vq.vq at model/features.py:1166 and
