@@ -328,11 +328,15 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 // some lane can improve, a register's candidate is ranked only when some lane's value in THAT
 // register passes (16 compares and wave-uniform branches instead of 16 updates).
 //
-// The gate of a lane is the larger of its running second best and `ref + band(ref)`, ref = the
-// running best (MODE2 false: the caller wants the nearest codeword) or the running second best
-// (MODE2 true: the caller wants both).  Everything below the gate is ranked, so at the end d3 is
-// the third smallest value among all candidates that matter: a candidate that was never ranked
-// lay, when it was seen, above ref + band(ref) of that moment, and both only shrink afterwards.
+// The gate of a lane is `ref + band(ref)`, ref = the running best (MODE2 false: the caller wants
+// the nearest codeword only) or the running second best (MODE2 true: the caller wants both).
+// Everything below the gate is ranked, so at the end the lane's list holds the three smallest
+// values among all candidates that matter: a candidate that was never ranked lay, when it was
+// seen, above ref + band(ref) of that moment, and both only shrink afterwards.  For a top-1
+// search this means the second and third entries are exact only inside the band of the best --
+// the only place k_rescore looks at them -- and a candidate between the band and the running
+// second best, which a plain top-2 search would have to rank, is skipped: about half the
+// ranking work of the top-2 gate.
 // Within a tile the gate of the tile's start is used (stale = larger = ranks a little more).
 template <int XT, bool MODE2>
 __device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top2 (&st)[XT],
@@ -360,7 +364,7 @@ __device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top
       st[xt].d3 = d3;
       st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
       st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
-      gate[xt] = __builtin_fmaxf(d2, __builtin_fmaf(MODE2 ? d2 : d1, 1.f + kBandSlope, c0[xt]));
+      gate[xt] = __builtin_fmaf(MODE2 ? d2 : d1, 1.f + kBandSlope, c0[xt]);
     }
   }
 }
