@@ -203,6 +203,10 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   const size_t o_xp = pad ? take((size_t)n * ic::kD * 4) : 0;
   const size_t o_cp = pad ? take((size_t)k * ic::kD * 4) : 0;
   const size_t o_thr = hint ? take((size_t)n * 4) : 0;
+  // index-only nearest-codeword calls: the search kernel leaves each row's band constant, and
+  // k_rescore settles most rows from the records alone
+  const bool index_only = !mode2 && !d1;
+  const size_t o_band = index_only ? take((size_t)n * 4) : 0;
   int rc;
   char* ws;
   if (use_static) {
@@ -248,12 +252,13 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     rc = profile_open(ctx, s, &ev1);
     if (rc) return rc;
   }
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, part, part3, s),
+  float* rowband = index_only ? reinterpret_cast<float*>(ws + o_band) : nullptr;
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, part, part3, rowband, s),
          "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   int32_t* list = reinterpret_cast<int32_t*>(ws + o_list);
   uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
-  IC_HIP(ic::launch_rescore(xs, n, cs, aux, part, part3, plan, mode2, i1, d1, i2, d2, ratio, mask,
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, part, part3, rowband, plan, mode2, i1, d1, i2, d2, ratio, mask,
                             rec, reinterpret_cast<uint8_t*>(ws + o_flags),
                             reinterpret_cast<uint32_t*>(ws + o_cnt), list, count, s),
          "rescore kernels");

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ aux, int stages_total, int split_base, int split_extra,
     int full_tiles, int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
-    float* __restrict__ part3) {
+    float* __restrict__ part3, float* __restrict__ rowband) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -534,6 +534,8 @@ __global__ __launch_bounds__(NW * 64) void k_top2_partial(
       const int64_t slot = part_slot(2 * sp + h, r, N, (int64_t)full_tiles * (XT * NW * 32));
       part[slot] = rec;
       part3[slot] = b.d3;
+      // the constant part of the row's band, for k_rescore's shortcut (same for every list)
+      if (rowband && sp == 0 && h == 0) rowband[r] = c0[xt];
     }
   }
 }
@@ -552,7 +554,7 @@ template <int NW, int SK>
 static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
                                   const float* aux, const AssignPlan& plan, bool mode2,
                                   const float* thr, ic_top2_rec* part, float* part3,
-                                  hipStream_t s) {
+                                  float* rowband, hipStream_t s) {
   const int64_t stages = (k + SK - 1) / SK;
   const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
   auto kern = !gated_variant() ? k_top2_partial<kXT, NW, SK, false, false>
@@ -563,7 +565,7 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
                      (int)stages, plan.split_base, plan.split_extra, (int)plan.full_tiles,
-                     (int)split_tiles, thr, part, part3);
+                     (int)split_tiles, thr, part, part3, rowband);
   return hipGetLastError();
 }
 
@@ -596,11 +598,12 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n) {
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const AssignPlan& plan, bool mode2,
-                               const float* thr, ic_top2_rec* part, float* part3, hipStream_t s) {
+                               const float* thr, ic_top2_rec* part, float* part3, float* rowband,
+                               hipStream_t s) {
   if (plan.waves == 8 && plan.stage_k == 64)
-    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, s);
+    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband, s);
   if (plan.waves == 16 && plan.stage_k == 128)
-    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, s);
+    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband, s);
   return hipErrorInvalidValue;
 }
 
@@ -689,15 +692,24 @@ __device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, floa
 // candidates of every row by direct differences, writes the outputs, and decides per row whether
 // the pair is certain to hold the answer (flags[row] = 0) or the row must be searched again by
 // direct differences (1); cnt[b] = number of its flagged rows.
+//
+// When only the index of the nearest codeword is wanted (rowband != NULL: the constant part of
+// each row's band, left by the search kernel), a first pass with one thread per row settles
+// every row whose second-best value lies outside the band of the best: no candidate can then be
+// nearer than the best by direct evaluation either, so its index is the answer and neither the
+// row nor any codeword is read again.  The other rows go through the pass below.
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
                                                  const float* __restrict__ aux,
                                                  const ic_top2_rec* __restrict__ part,
-                                                 const float* __restrict__ part3, int nsplit,
+                                                 const float* __restrict__ part3,
+                                                 const float* __restrict__ rowband, int nsplit,
                                                  int64_t split_row0, int mode2, int64_t chunk,
                                                  FinalOut out, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ cnt) {
   __shared__ int wcnt[16];
+  __shared__ int todo[256];
+  __shared__ int ntodo;
   const int sub = threadIdx.x & 15;
   const int grp = threadIdx.x >> 4;
   const int64_t row_begin = (int64_t)blockIdx.x * chunk;
@@ -705,8 +717,9 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   const f32x4 m0 = *reinterpret_cast<const f32x4*>(aux + sub * 8);
   const f32x4 m1 = *reinterpret_cast<const f32x4*>(aux + sub * 8 + 4);
   const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
-  int nflag = 0;
-  for (int64_t row = row_begin + grp; row < row_end; row += 16) {
+
+  // one row, by the 16 lanes of a group; returns whether the row needs the direct search
+  auto full_look = [&](int64_t row) -> bool {
     ic_top2_rec b = part[row];
     float v3 = part3[row];
     // lists of this row: the two lane halves of every K-split (rows below split_row0 were not split)
@@ -772,7 +785,39 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     if (sub == 0) {
       write_final(out, row, s1, a1, s2, a2);
       flags[row] = unsure ? 1 : 0;
-      nflag += unsure ? 1 : 0;
+    }
+    return unsure;
+  };
+
+  int nflag = 0;
+  if (rowband == nullptr) {
+    for (int64_t row = row_begin + grp; row < row_end; row += 16) nflag += full_look(row) ? 1 : 0;
+  } else {
+    for (int64_t base = row_begin; base < row_end; base += 256) {   // uniform trip count
+      if (threadIdx.x == 0) ntodo = 0;
+      __syncthreads();
+      const int64_t row = base + threadIdx.x;
+      if (row < row_end) {
+        ic_top2_rec b = part[row];
+        const int ns = row >= split_row0 ? 2 * nsplit : 2;
+        for (int s = 1; s < ns; ++s) {
+          const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
+          top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
+        }
+        // the gate's band of the best: everything outside the pair lies above b.d2 or was
+        // never ranked, and what was never ranked lies above this band as well
+        const float band = __builtin_fmaf(b.d1, kBandSlope, rowband[row]);
+        if (b.i1 >= 0 && (b.d2 - b.d1) > band) {   // false on NaN
+          out.i1[row] = b.i1;
+          flags[row] = 0;
+        } else {
+          todo[atomicAdd(&ntodo, 1)] = (int)threadIdx.x;   // any order: rows are independent
+        }
+      }
+      __syncthreads();
+      const int nt = ntodo;
+      for (int t = grp; t < nt; t += 16) nflag += full_look(base + todo[t]) ? 1 : 0;
+      __syncthreads();
     }
   }
   if (sub == 0) wcnt[grp] = nflag;
@@ -829,15 +874,17 @@ int64_t rescore_chunk(int64_t n) {
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const ic_top2_rec* part, const float* part3, const AssignPlan& plan,
-                          bool mode2, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                          const ic_top2_rec* part, const float* part3, const float* rowband,
+                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
                           uint8_t* mask, ic_top2_rec* rec, uint8_t* flags, uint32_t* cnt,
                           int32_t* list, uint32_t* count, hipStream_t s) {
   const int64_t chunk = rescore_chunk(n);
   const int64_t grid = (n + chunk - 1) / chunk;
   if (grid < 1 || n >= 0x7fffffffLL) return hipErrorInvalidValue;
+  // the shortcut answers with an index only
+  if (rowband && (mode2 || d1 || !i1)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, part, part3,
-                     plan.nsplit, plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
+                     rowband, plan.nsplit, plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, flags, cnt);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -48,9 +48,11 @@ hipError_t launch_codebook_aux(const float* c, int64_t k, float* aux, char* scra
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
 // part [assign_part_records]: per K-split (|c-m|^2 - 2 (x-m).c, index) best and second best;
 // part3 the value of the third best.  mode2: the caller wants the second neighbour too.
+// rowband (may be NULL) [n]: the constant part of each row's band, for launch_rescore's shortcut.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const AssignPlan& plan, bool mode2,
-                               const float* thr, ic_top2_rec* part, float* part3, hipStream_t s);
+                               const float* thr, ic_top2_rec* part, float* part3, float* rowband,
+                               hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
                                  const float* aux, const int32_t* hint, float* thr,
@@ -58,12 +60,14 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
 // merge the K-splits, evaluate the two candidates as sum (x-c)^2, order, sqrt, ratio test; flag
 // the rows whose pair is not certain to hold the answer and list them (ascending) with their
 // number.  flags [n] u8, cnt [ceil(n / rescore_chunk(n))] u32, list [n] i32, count [1] u32.
+// rowband != NULL (only i1 wanted, top-1): rows whose second-best value lies outside the band of
+// the best are answered from the records alone.
 int64_t rescore_chunk(int64_t n);
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const ic_top2_rec* part, const float* part3, const AssignPlan& plan,
-                          bool mode2, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                          uint8_t* mask, ic_top2_rec* rec, uint8_t* flags, uint32_t* cnt,
-                          int32_t* list, uint32_t* count, hipStream_t s);
+                          const ic_top2_rec* part, const float* part3, const float* rowband,
+                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, uint8_t* flags,
+                          uint32_t* cnt, int32_t* list, uint32_t* count, hipStream_t s);
 // search the listed rows again by direct differences and overwrite their outputs.
 // partial: 16 * kExactGrid records.
 hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,

@@ -191,6 +191,10 @@ def _same_as_direct(x, c, ratio=0.8):
         idx, dist = ops.assign_top1(xd, cd)
         torch.cuda.synchronize()
         flagged1 = int(counter.item())
+        # index only: most rows are settled from the search records alone
+        idx_only, none = ops.assign_top1(xd, cd, want_dist=False)
+        torch.cuda.synchronize()
+        flagged0 = int(counter.item())
     finally:
         ops.debug_flagged(0, None)
     direct = ops.assign_top2_exact(xd, cd, ratio)
@@ -200,6 +204,8 @@ def _same_as_direct(x, c, ratio=0.8):
         assert bad == 0, "%s differs from the direct search on %d of %d rows" % (name, bad, len(a))
     assert torch.equal(idx, direct[0])
     assert torch.equal(dist.view(torch.int32), direct[1].view(torch.int32))
+    assert none is None and torch.equal(idx_only, direct[0])
+    assert flagged0 <= flagged1      # the shortcut sends no additional row to the second look
     return flagged1, flagged2
 
 

@@ -60,6 +60,10 @@ def main():
         hint[1::7] = -5
         h1, hd1 = ops.assign_top1(x, c, hint=hint)
         assert torch.equal(h1, i1) and torch.equal(hd1, d1), tag + ": hinted search differs"
+        # index only, with and without the hint: the same indices
+        o1, _ = ops.assign_top1(x, c, want_dist=False)
+        o2, _ = ops.assign_top1(x, c, want_dist=False, hint=hint)
+        assert torch.equal(o1, e1) and torch.equal(o2, e1), tag + ": index-only search differs"
         # record + merge over two ragged index shards
         if k >= 2:
             cut = int(rng.integers(1, k))
