@@ -1019,6 +1019,10 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
       reinterpret_cast<f32x4*>(&xs[r][0])[q] = reinterpret_cast<const f32x4*>(X + rows[r] * kD)[q];
     }
     __syncthreads();
+    // rows of this group that exist (the last group of a short list is mostly padding, and a
+    // short list is the usual case of the second look): uniform, so the guards below are scalar
+    // branches
+    const int nr = total - g * kExactRows < kExactRows ? (int)(total - g * kExactRows) : kExactRows;
     float d1[kExactRows], d2[kExactRows];
     int i1[kExactRows], i2[kExactRows];
 #pragma unroll
@@ -1037,13 +1041,16 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
 #pragma unroll
         for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + blk * 32 + q * 4);
 #pragma unroll
-        for (int r = 0; r < kExactRows; ++r) acc[r] += block32(&xs[r][blk * 32], cv);
+        for (int r = 0; r < kExactRows; ++r)
+          if (r < nr) acc[r] += block32(&xs[r][blk * 32], cv);
       }
 #pragma unroll
-      for (int r = 0; r < kExactRows; ++r) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
+      for (int r = 0; r < kExactRows; ++r)
+        if (r < nr) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
     }
 #pragma unroll
     for (int r = 0; r < kExactRows; ++r) {
+      if (r >= nr) continue;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
         const float od1 = __shfl_xor(d1[r], off), od2 = __shfl_xor(d2[r], off);
