@@ -38,6 +38,7 @@
 // over the whole codebook (k_exact_rows).  The direct-difference arithmetic is the same function in
 // both places, so results equal those of the all-direct search (ic_assign_top2_exact) on every row.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ic_internal.h"
 
@@ -1030,24 +1031,30 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
       d1[r] = d2[r] = __builtin_inff();
       i1[r] = i2[r] = -1;
     }
-    for (int j = k0 + (int)threadIdx.x; j < k1; j += 256) {
-      const float* crow = C + (int64_t)j * kD;
-      float acc[kExactRows];
+    // two copies of the scan: a full group runs without the per-row guards
+    auto scan = [&](auto full_tag) {
+      constexpr bool kFull = decltype(full_tag)::value;
+      for (int j = k0 + (int)threadIdx.x; j < k1; j += 256) {
+        const float* crow = C + (int64_t)j * kD;
+        float acc[kExactRows];
 #pragma unroll
-      for (int r = 0; r < kExactRows; ++r) acc[r] = 0.f;
+        for (int r = 0; r < kExactRows; ++r) acc[r] = 0.f;
 #pragma unroll 1
-      for (int blk = 0; blk < 4; ++blk) {
-        f32x4 cv[8];
+        for (int blk = 0; blk < 4; ++blk) {
+          f32x4 cv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + blk * 32 + q * 4);
+          for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + blk * 32 + q * 4);
+#pragma unroll
+          for (int r = 0; r < kExactRows; ++r)
+            if (kFull || r < nr) acc[r] += block32(&xs[r][blk * 32], cv);
+        }
 #pragma unroll
         for (int r = 0; r < kExactRows; ++r)
-          if (r < nr) acc[r] += block32(&xs[r][blk * 32], cv);
+          if (kFull || r < nr) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
       }
-#pragma unroll
-      for (int r = 0; r < kExactRows; ++r)
-        if (r < nr) top2_update(d1[r], d2[r], i1[r], i2[r], acc[r], j);
-    }
+    };
+    if (nr == kExactRows) scan(std::true_type{});
+    else scan(std::false_type{});
 #pragma unroll
     for (int r = 0; r < kExactRows; ++r) {
       if (r >= nr) continue;
