@@ -35,6 +35,8 @@ _SIGNATURES = {
     "ic_create": [_c_int, ctypes.POINTER(_p)],
     "ic_destroy": [_p],
     "ic_last_error": [_p],
+    "ic_reserve_workspace": [_p, ctypes.c_size_t],
+    "ic_workspace_bytes": [_p, ctypes.POINTER(ctypes.c_size_t)],
     "ic_profile_begin": [_p],
     "ic_profile_end": [_p, ctypes.POINTER(_c_d), ctypes.POINTER(_c_i64)],
     "ic_row_sqnorm": [_p, _p, _c_i64, _c_int, _p, _p],

@@ -85,19 +85,22 @@ struct DeviceGuard {
   }
 };
 
-// Grow-only workspace.  Growing waits for everything in flight on the device before the old
-// block is released.
+// Grow-only workspace.  Only this handle's calls use it, each ordered after the one before
+// (order_after_previous / finish_call), so growing waits for the handle's last call -- not for
+// the device -- before the old block is released.  ic_reserve_workspace sizes it up front.
 int ensure_ws(Ctx* c, size_t bytes) {
   if (bytes <= c->ws_bytes) return IC_OK;
-  hipError_t e = hipDeviceSynchronize();
-  if (e != hipSuccess) return fail_hip(e, "hipDeviceSynchronize before workspace growth");
+  if (c->have_last) {
+    hipError_t e = hipEventSynchronize(c->done);
+    if (e != hipSuccess) return fail_hip(e, "hipEventSynchronize before workspace growth");
+  }
   if (c->ws) {
     (void)hipFree(c->ws);
     c->ws = nullptr;
     c->ws_bytes = 0;
   }
   const size_t want = align_up(bytes + bytes / 4, 1 << 20);
-  e = hipMalloc(reinterpret_cast<void**>(&c->ws), want);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->ws), want);
   if (e != hipSuccess) {
     c->ws = nullptr;
     return fail(IC_ENOMEM, "workspace allocation of %zu bytes failed: %s", want,
@@ -343,6 +346,24 @@ int ic_destroy(void* handle) {
     c->magic = 0;
   }
   delete c;
+  return IC_OK;
+}
+
+int ic_reserve_workspace(void* handle, size_t bytes) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_reserve_workspace: invalid handle");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
+  return ensure_ws(ctx, bytes);
+}
+
+int ic_workspace_bytes(void* handle, size_t* bytes) {
+  Ctx* ctx = as_ctx(handle);
+  if (!ctx) return fail(IC_EHANDLE, "ic_workspace_bytes: invalid handle");
+  if (!bytes) return fail(IC_EINVAL, "ic_workspace_bytes: bytes is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  *bytes = ctx->ws_bytes;
   return IC_OK;
 }
 

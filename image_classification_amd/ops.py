@@ -637,6 +637,21 @@ def ransac_homography(pts, offsets, n_iter, th, samples=None, seed=0, min_inlier
     return H, n_inl, err, best_it, mask
 
 
+def reserve_workspace(device_index, nbytes):
+    """Grow the handle's device workspace to at least `nbytes` now, so that later calls of known
+    size do not allocate."""
+    _lib.check(_lib.load().ic_reserve_workspace(_lib.handle(device_index), int(nbytes)),
+               "ic_reserve_workspace")
+
+
+def workspace_bytes(device_index):
+    """Current size of the handle's device workspace."""
+    out = ctypes.c_size_t(0)
+    _lib.check(_lib.load().ic_workspace_bytes(_lib.handle(device_index), ctypes.byref(out)),
+               "ic_workspace_bytes")
+    return int(out.value)
+
+
 def profile_begin(device_index):
     """Start timing the distance kernel of every following assign call on this device."""
     _lib.check(_lib.load().ic_profile_begin(_lib.handle(device_index)), "ic_profile_begin")

@@ -24,6 +24,7 @@
 #ifndef IC_HIP_H
 #define IC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -66,6 +67,15 @@ int ic_version(void);
 int ic_create(int device, void** handle);
 int ic_destroy(void* handle);
 const char* ic_last_error(void* handle); /* handle may be NULL: error of the last failed ic_create */
+
+/* The handle's device workspace (partial results of the calls below) grows on demand: a call
+ * that needs more than the handle holds waits for the handle's previous call, frees the block and
+ * allocates a larger one.  ic_reserve_workspace does that up front (grow only; at least `bytes`
+ * afterwards), so that a loop of calls of known size never allocates; ic_workspace_bytes reports
+ * the current size -- run the largest call once, read it, reserve that on the next start.  No
+ * counterpart in the reference. */
+int ic_reserve_workspace(void* handle, size_t bytes);
+int ic_workspace_bytes(void* handle, size_t* bytes);
 
 /* Timing of the distance kernel with HIP events recorded on the caller's stream, one pair per
  * ic_assign_* call (the descriptor search kernel) or per ic_knn_rows batch (the pairwise distance

@@ -424,3 +424,27 @@ def test_errors_are_loud():
         ops.assign_top1(_dev(np.zeros((4, 200))), _dev(np.zeros((3, 200))))
     with pytest.raises(ValueError):
         ops.assign_top1(x.cpu(), x)
+
+
+def test_reserved_workspace_is_not_reallocated():
+    # a workspace sized up front: calls that fit it leave its size (and the device's free memory)
+    # alone; a larger call grows it, and the results are the same either way
+    x = _dev(sift_like(50_000, seed=61))
+    c = _dev(sift_like(700, seed=62))
+    before = ops.assign_top2(x, c, 0.8)
+    torch.cuda.synchronize()
+    need = ops.workspace_bytes(0)
+    assert need > 0
+    ops.reserve_workspace(0, 4 * need)
+    size = ops.workspace_bytes(0)
+    assert size >= 4 * need
+    free0 = torch.cuda.mem_get_info()[0]
+    for n in (50_000, 20_000, 100_000):
+        got = ops.assign_top2(x[:n] if n <= 50_000 else torch.cat([x, x]), c, 0.8)
+        torch.cuda.synchronize()
+        assert ops.workspace_bytes(0) == size
+        if n == 50_000:
+            assert all(torch.equal(a, b) for a, b in zip(got, before))
+    assert torch.cuda.mem_get_info()[0] == free0
+    ops.reserve_workspace(0, 1)                       # grow only
+    assert ops.workspace_bytes(0) == size
