@@ -103,12 +103,22 @@ def rank_command(n_ranks, argv, port=None):
             "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def rank_environment(n_ranks, env=None):
+    """Defaults every rank needs BEFORE torch is imported, whoever started it (this script's own
+    launcher, or torch.distributed.run directly): the host driver shares device memory between
+    processes through dmabuf only, so RCCL's peer-to-peer set-up and any tensor sharing fail with
+    `hipIpcGetMemHandle: invalid argument` unless HSA_ENABLE_IPC_MODE_LEGACY=0; and N ranks must
+    not each start a BLAS pool as wide as the machine."""
+    env = os.environ if env is None else env
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n_ranks) // 2)))
+    return env
+
+
 def launch_ranks(n_ranks, argv):
     """Start the ranks as a CHILD process (never exec: a launcher must stay a plain parent) and
     pass its exit status on.  The ranks inherit stdout, so rank 0's JSON line appears here."""
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver supports dmabuf IPC only
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n_ranks) // 2)))
+    env = rank_environment(n_ranks, dict(os.environ))
     return subprocess.call(rank_command(n_ranks, argv), env=env)
 
 
@@ -125,8 +135,10 @@ def parse_args(argv=None):
                     help="bow / video / cfg1: order the codebook by descending distance to the "
                          "data mean, so that later codewords keep improving the running top-2 "
                          "(the worst case for the kernel's ranking gate)")
-    ap.add_argument("--cpu-sample", type=int, default=400_000,
-                    help="rows of the workload the CPU baseline is timed on (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="rows of the workload the CPU baseline is timed on (0 = skip; -1 = the "
+                         "whole workload when a probe estimates it under 60 s on all BLAS "
+                         "threads, else the share that takes about 30 s)")
     ap.add_argument("--no-comm", action="store_true",
                     help="skip the k-means / index-sharded 2-NN sub-records of the default workload")
     ap.add_argument("--force-dist", action="store_true",
@@ -138,7 +150,11 @@ def parse_args(argv=None):
                     help="ranks only rendezvous over gloo on the CPU and report themselves "
                          "(tests the launcher where there is no GPU)")
     ap.add_argument("--comm-timeout", type=float, default=240.0,
-                    help="seconds after which rank 0 prints the line without the comm records")
+                    help="seconds after which rank 0 prints the line without the comm records "
+                         "and the process exits with status 3")
+    ap.add_argument("--inject-comm-failure", choices=["", "raise", "hang"], default="",
+                    help="test hook: make the comm sub-records fail (raise) or never finish "
+                         "(hang), to check that the exit status reports it")
     return ap.parse_args(argv)
 
 
@@ -179,14 +195,16 @@ def cpu_baseline(x_sample, codebook32, per_image, norm):
     codes, _h = ref.bow_quantize(images, vocab64, norm)
     dt = time.perf_counter() - t0
     code = np.concatenate(codes)
+    # the secondary legs (one thread, the numpy port, the scikit-learn argmin) run on the first
+    # quarter of the sample, so that the whole baseline stays bounded
+    ns = max(per_image, n // 4 // per_image * per_image)
     one_core = dt1 = None
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
             t1 = time.perf_counter()
-            ref.bow_quantize(images, vocab64, norm)
+            ref.bow_quantize(images[:ns // per_image], vocab64, norm)
             dt1 = time.perf_counter() - t1
-            one_core = n / dt1
-    ns = max(per_image, n // 4 // per_image * per_image)
+            one_core = ns / dt1
     t2 = time.perf_counter()
     pcode, _ = oracle.vq(x_sample[:ns], codebook32)
     oracle.build_histogram([pcode[i * per_image:(i + 1) * per_image] for i in range(ns // per_image)],
@@ -207,9 +225,33 @@ def cpu_baseline(x_sample, codebook32, per_image, norm):
             "sample": "%d rows = %d images of the workload, same vocabulary: the reference's own "
                       "calls (scipy.cluster.vq.vq per image, float32 rows / float64 vocabulary, "
                       "+ np.histogram + %s norm; the reference's Python 2 modules cannot be "
-                      "imported), %.1f s on %d BLAS threads%s; port and sklearn legs on the first "
-                      "%d rows" % (n, n_img, norm, dt, blas_threads,
-                                   ", %.1f s on one" % dt1 if dt1 else "", ns)}, code
+                      "imported), %.1f s on %d BLAS threads; one-thread%s, port and sklearn legs "
+                      "on the first %d rows" % (n, n_img, norm, dt, blas_threads,
+                                                " (%.1f s)" % dt1 if dt1 else "", ns)}, code
+
+
+def choose_cpu_sample(requested, x, codebook32, per_image, norm):
+    """Rows of the workload the CPU baseline runs on.  A non-negative request is taken as given;
+    -1 times the reference's calls on a few images and takes the whole workload when that
+    predicts under 60 s on all BLAS threads, else the share that takes about 30 s."""
+    import numpy as np
+    from oracle import reference_calls as ref
+    n_rows = x.shape[0]
+    if requested >= 0:
+        return min(requested, n_rows) // per_image * per_image
+    if ref.versions()["scipy"] is None:
+        return min(n_rows, 100_000) // per_image * per_image
+    n_probe = max(1, min(n_rows // per_image, max(8, 16_000 // per_image)))
+    probe = x[:n_probe * per_image].cpu().numpy()
+    imgs = [probe[i * per_image:(i + 1) * per_image] for i in range(n_probe)]
+    vocab64 = codebook32.astype(np.float64)
+    ref.bow_quantize(imgs[:2], vocab64, norm)   # warm the BLAS pool
+    t0 = time.perf_counter()
+    ref.bow_quantize(imgs, vocab64, norm)
+    rate = n_probe * per_image / (time.perf_counter() - t0)
+    if n_rows / rate <= 60.0:
+        return n_rows // per_image * per_image
+    return max(per_image, int(30.0 * rate) // per_image * per_image)
 
 
 def cpu_baseline_logo(x, kp_rows, q, kp_q, per, n_logos, n_iter, gpu_inliers, gpu_off):
@@ -243,19 +285,21 @@ def cpu_baseline_logo(x, kp_rows, q, kp_q, per, n_logos, n_iter, gpu_inliers, gp
 
 
 def measured_traffic(workload, kernel="k_top2_partial"):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary of this
-    workload (profiles/rNN_<workload>_traffic.json)."""
+    """(HBM bytes per launch of the dominant kernel, the file it was read from): the newest
+    committed PMC summary of this workload, profiles/rNN_<workload>_traffic.json.  The counters
+    need rocprofv3 passes of their own, so this is a figure of the committed profile, not of the
+    run that prints it; the line says which file."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % workload)))
     if not files:
-        return None
+        return None, None
     try:
         data = json.load(open(files[-1]))
         for name, rec in data.items():
             if kernel in name:
-                return float(rec["hbm_bytes_per_launch"])
+                return float(rec["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
-    return None
+        return None, None
+    return None, None
 
 
 def adverse_order(cb, x):
@@ -406,6 +450,44 @@ def comm_records(torch, dist, fence, D, backend, dev, rank, world, use_dist, dis
 
 
 # ---------------------------------------------------------------------------------------------
+COMM_FAILED_STATUS = 3   # exit status of a rank whose comm sub-records failed or never finished
+
+
+def guarded_comm(out, rank, timeout, inject, body):
+    """Run `body()` -- the sub-records that exchange data between ranks -- so that neither an
+    exception nor a stuck collective can lose the headline line or pass for success.
+
+    Returns (record, exit_status).  An exception becomes {"error": ...} with COMM_FAILED_STATUS.
+    A body that has not returned after `timeout` seconds cannot be interrupted (the thread sits
+    inside a collective or a device wait): rank 0 prints the line it has, with comm.error, and
+    the process ends at once with COMM_FAILED_STATUS, so the launcher and whoever runs it see a
+    failure."""
+    def give_up():
+        if rank == 0 and out is not None:
+            out["comm"] = {"error": "sub-records did not finish within %.0f s" % timeout}
+            print(json.dumps(out), flush=True)
+        sys.stderr.write("bench.py: rank %d: comm sub-records stuck, exiting with status %d\n"
+                         % (rank, COMM_FAILED_STATUS))
+        sys.stderr.flush()
+        os._exit(COMM_FAILED_STATUS)
+
+    watchdog = threading.Timer(timeout, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+    status = 0
+    try:
+        if inject == "raise":
+            raise RuntimeError("injected comm failure")
+        if inject == "hang":
+            threading.Event().wait()
+        comm = body()
+    except Exception as e:   # the headline line must survive a failing sub-record
+        comm = {"error": "%s: %s" % (type(e).__name__, e)}
+        status = COMM_FAILED_STATUS
+    watchdog.cancel()
+    return comm, status
+
+
 def launch_check(args):
     """Ranks rendezvous over gloo on the CPU and rank 0 reports who came: the launcher's test."""
     import torch
@@ -419,13 +501,20 @@ def launch_check(args):
         t[rank] = os.getpid()
         dist.all_reduce(t)
         pids = [int(v) for v in t]
+    out = {"launch_check": True, "n_gpus": world, "requested": args.gpus, "rank_pids": pids,
+           "launcher_pid": os.getppid(),
+           "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS",
+                                                  "MASTER_ADDR", "MASTER_PORT")}}
+    status = 0
+    if args.inject_comm_failure:
+        out["comm"], status = guarded_comm(out if rank == 0 else None, rank, args.comm_timeout,
+                                           args.inject_comm_failure, lambda: {})
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "requested": args.gpus,
-                          "rank_pids": pids, "launcher_pid": os.getppid()}), flush=True)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return status
 
 
 def run_rank(args):
@@ -438,6 +527,7 @@ def run_rank(args):
                          "or let `python bench.py --gpus %d` do it\n"
                          % (args.gpus, world, args.gpus, args.gpus, args.gpus))
         return 2
+    rank_environment(world)   # before torch is imported: also for ranks torch.distributed.run started
     if args.launch_check:
         return launch_check(args)
 
@@ -454,7 +544,11 @@ def run_rank(args):
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise SystemExit("bench.py: MASTER_PORT is not set; ranks are started by "
+                                 "torch.distributed.run (or by `python bench.py --gpus N`)")
+            os.environ["MASTER_PORT"] = str(_free_port())   # one rank: any free port will do
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -599,18 +693,22 @@ def run_rank(args):
         avg_kernel_s = kern_ms / max(1, launches) / 1e3
         is_pairs = args.workload == "knn"
         is_hist = args.workload == "histknn"
+        traffic, traffic_src = measured_traffic(
+            args.workload, "k_pairdist_few" if is_hist else "k_top2_partial")
+        traffic_note = ("rocprofv3 --pmc passes of this workload, committed as %s (not measured "
+                        "by this run)" % traffic_src) if traffic_src else None
         if is_hist:
             achieved = bytes_per_launch / avg_kernel_s / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": measured_traffic(args.workload, "k_pairdist_few"),
+                        "traffic": traffic, "traffic_source": traffic_note,
                         "kernel": "k_pairdist_few", "avg_kernel_ms": avg_kernel_s * 1e3,
                         "bytes_per_launch": bytes_per_launch}
         else:
             achieved = flops_per_launch / avg_kernel_s / 1e12
             roofline = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                        "traffic": measured_traffic(args.workload),
+                        "traffic": traffic, "traffic_source": traffic_note,
                         "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
                         "flops_per_launch": flops_per_launch,
                         "peak_basis": "256 CU x 256 FLOP/clk x 2.4 GHz; this device reports "
@@ -652,16 +750,15 @@ def run_rank(args):
                        "dist_backend": args.dist_backend if use_dist else None},
             "roofline": roofline,
         }
-        if world == 1 and args.cpu_sample > 0 and quantising:
+        if world == 1 and args.cpu_sample != 0 and quantising:
             per_image = n_rows // w["images"]
-            ns = min(args.cpu_sample, n_rows)
-            ns -= ns % per_image
+            ns = choose_cpu_sample(args.cpu_sample, x, cb.cpu().numpy(), per_image, w["norm"])
             base, ref_code = cpu_baseline(x[:ns].cpu().numpy(), cb.cpu().numpy(), per_image, w["norm"])
             base["agreement_with_gpu"] = float(np.mean(ref_code == out_a[:ns].cpu().numpy()))
             out["cpu_baseline"] = base
         if phases is not None:
             out["config"]["phase_ms"] = phases
-        if quantising and args.cpu_sample > 0:
+        if quantising and args.cpu_sample != 0:
             # every row of the workload against the direct float32 search on the device (no norm
             # expansion; outside the timed region)
             e1, ed1, _e2, ed2, _m = ops.assign_top2_exact(x, cb)
@@ -670,11 +767,12 @@ def run_rank(args):
                              "agreement": float((out_a == e1).float().mean()),
                              "mismatches": int((out_a != e1).sum()),
                              "mismatches_where_gap_exceeds_1e-5": int(((out_a != e1) & gap).sum())}
-        if world == 1 and args.cpu_sample > 0 and args.workload == "logo":
+        if world == 1 and args.cpu_sample != 0 and args.workload == "logo":
+            logo_rows = args.cpu_sample if args.cpu_sample > 0 else 400_000
             out["cpu_baseline"] = cpu_baseline_logo(
-                x, kp_rows, q, kp_q, per, max(1, min(n_img, args.cpu_sample // per // 2)), n_iter,
+                x, kp_rows, q, kp_q, per, max(1, min(n_img, logo_rows // per // 2)), n_iter,
                 out_a, out_b)
-        if world == 1 and args.cpu_sample > 0 and is_pairs:
+        if world == 1 and args.cpu_sample != 0 and is_pairs:
             # measured agreement of the index-sharded search with the float64 oracle on a sample
             import oracle
             nq_s, ni_s = 500, 200_000
@@ -689,32 +787,28 @@ def run_rank(args):
                              "mismatches_where_gap_exceeds_1e-5": [bad1, bad2],
                              "max_rel_distance_error": oracle.check_close(d1s.cpu().numpy(), rd[:, 0])}
 
+    status = 0
     if args.workload == "bow" and not args.no_comm and not args.adverse:
         # free the headline workload's buffers, then the two communicating sub-paths; should they
-        # not finish in time, rank 0 still prints the line it has
-        def give_up():
-            if rank == 0 and out is not None:
-                out["comm"] = {"error": "sub-records did not finish within %.0f s" % args.comm_timeout}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        watchdog = threading.Timer(args.comm_timeout, give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            del x, out_a, out_b
-            torch.cuda.empty_cache()
-            comm = comm_records(torch, dist, fence, D, backend, dev, rank, world, use_dist,
-                                args.dist_backend)
-        except Exception as e:   # the headline line must survive a failing sub-record
-            comm = {"error": "%s: %s" % (type(e).__name__, e)}
-        watchdog.cancel()
+        # fail or not finish in time, rank 0 still prints the line it has and the exit status is
+        # COMM_FAILED_STATUS
+        del x, out_a, out_b
+        torch.cuda.empty_cache()
+        comm, status = guarded_comm(
+            out, rank, args.comm_timeout, args.inject_comm_failure,
+            lambda: comm_records(torch, dist, fence, D, backend, dev, rank, world, use_dist,
+                                 args.dist_backend))
         if out is not None:
             out["comm"] = comm
 
     if rank == 0:
         print(json.dumps(out), flush=True)
 
+    if status != 0:
+        # a failed collective may have left the process group unusable: no barrier, no teardown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(status)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

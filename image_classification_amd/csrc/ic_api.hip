@@ -320,7 +320,8 @@ int ic_create(int device, void** handle) {
   if (e != hipSuccess || !sp) {
     (void)hipEventDestroy(c->done);
     delete c;
-    return fail_hip(e, "hipGetSymbolAddress(scratch)");
+    if (e != hipSuccess) return fail_hip(e, "hipGetSymbolAddress(scratch)");
+    return fail(IC_EINVAL, "ic_create: hipGetSymbolAddress(scratch) returned a NULL address");
   }
   c->static_scratch = static_cast<char*>(sp);
   *handle = c;

@@ -6,9 +6,11 @@ the kernels read stays in HBM between calls; it is looked up by a hash of the ho
 contents, so an array that was edited in place (or freed and reallocated at the same address)
 never finds a stale copy.  Hashing costs about as much as reading the array once (xxh3: ~0.1 ms
 per MB), a fraction of the conversion + upload + auxiliary block it saves; a caller that wants
-not even that freezes its vocabulary (`vocab.setflags(write=False)`: a read-only array that is
-still the same object is recognised without reading it) or passes a `ResidentCodebook` it built
-once.
+not even that passes a `ResidentCodebook` it built once, or an array over memory numpy can never
+write to (`np.frombuffer(bytes)`, `np.load(..., mmap_mode="r")`): such an array, while it is still
+the same object, is recognised without reading it.  A read-only flag alone is not enough -- an
+owning array can be made writable, edited and frozen again between two calls -- so those are
+hashed like any other.
 """
 import os
 import threading
@@ -74,13 +76,23 @@ def _fingerprint(a):
 
 
 def _frozen(a):
-    """True when nothing can change the array's contents through numpy: it is read-only, and so
-    is every array it is a view of (a read-only view of a writable base can still change)."""
+    """True when nothing can change the array's contents through numpy, now or later: it is
+    read-only, so is every array it is a view of (a read-only view of a writable base can still
+    change), and the memory at the end of that chain is a read-only buffer numpy does not own
+    (bytes, a read-only mmap).  An array that owns its memory is never trusted: `setflags` can
+    thaw it, and the next call would find it frozen again with other contents."""
     while isinstance(a, np.ndarray):
         if a.flags.writeable:
             return False
         a = a.base
-    return a is None or isinstance(a, (bytes, str))
+    if a is None:
+        return False
+    if isinstance(a, (bytes, str)):
+        return True
+    try:
+        return bool(memoryview(a).readonly)
+    except TypeError:
+        return False
 
 
 _cache = {}
@@ -100,9 +112,11 @@ def resident(codebook, device=None):
     a = np.asarray(codebook)
     if a.ndim != 2:
         raise ValueError("codebook must be 2-D, got shape %s" % (a.shape,))
-    # A frozen array (`vocab.setflags(write=False)`) that is still the same Python object cannot
-    # have changed: it is recognised without reading a byte -- per-image calls as the reference
-    # issues them then cost no hash at all.
+    if a.shape[0] == 0 or a.shape[1] == 0:
+        raise ValueError("empty codebook (shape %s)" % (a.shape,))
+    # An array over immutable memory that is still the same Python object cannot have changed: it
+    # is recognised without reading a byte -- per-image calls as the reference issues them then
+    # cost no hash at all.
     fkey = (os.getpid(), str(device), id(a))
     if _frozen(a):
         with _cache_lock:

@@ -13,7 +13,6 @@ one device call builds every histogram.
 `norm` is an extension: 'l1' is the reference's normalisation, 'l2', 'power_l2' and 'none' are
 additional modes with no counterpart in the reference.
 """
-import importlib
 import json
 import os
 
@@ -23,7 +22,19 @@ from .backend import default_backend
 from .clustering import kmeans_fit
 from .imagedesc import ImageDesc
 
-__all__ = ["BagOfWords", "SpatialBagOfWords", "Vocabulary"]
+__all__ = ["BagOfWords", "SpatialBagOfWords", "Vocabulary", "register_component"]
+
+# Classes a model directory's manifest may name.  A manifest is data from disk: it can only select
+# among classes the running program has registered (or handed to load_from_dir), never make the
+# loader import a module of its choosing.
+_COMPONENTS = {}
+
+
+def register_component(klass):
+    """Class decorator: allow `klass` (a feature extractor or projection with `save_to_file` /
+    `load_from_file`) to be named in a model directory's manifest."""
+    _COMPONENTS[_import_path(klass)] = klass
+    return klass
 
 
 class Vocabulary(object):
@@ -94,9 +105,11 @@ class BagOfWords(object):
     normalisation, the import paths of the extractor / projection classes, any subclass
     parameters) next to `vocab.npy` -- the one file both layouts share -- and lets the extractor
     and the projection write their own files through their `save_to_file`.  `load_from_dir`
-    imports the classes named in the manifest and calls their `load_from_file`; nothing is
-    unpickled.  A directory written by the reference (no manifest) still yields its vocabulary:
-    pass the extractor (and projection) objects to `load_from_dir` in that case.
+    looks the class names of the manifest up among the classes registered with
+    `register_component` (or passed as `components=`) and calls their `load_from_file`; nothing
+    is unpickled and no module is imported on the manifest's say-so.  A directory written by the
+    reference (no manifest) still yields its vocabulary: pass the extractor (and projection)
+    objects to `load_from_dir` in that case.
     """
     MANIFEST = "bow.json"
     VOCAB_FILE = "vocab.npy"
@@ -227,18 +240,34 @@ class BagOfWords(object):
             json.dump(manifest, f, indent=1, sort_keys=True)
 
     @classmethod
-    def load_from_dir(cls, model_dir, feat_ext=None, projection=None, backend=None):
+    def load_from_dir(cls, model_dir, feat_ext=None, projection=None, backend=None,
+                      components=None):
+        """`components`: classes (a list, or a mapping 'module:Class' -> class) the manifest may
+        name in addition to those registered with `register_component`."""
         vocab = np.load(os.path.join(model_dir, cls.VOCAB_FILE), allow_pickle=False)
-        manifest = {"norm": "l1", "power": 0.5, "components": {}, "params": {}}
+        manifest = {"format": 1, "norm": "l1", "power": 0.5, "components": {}, "params": {}}
         path = os.path.join(model_dir, cls.MANIFEST)
         if os.path.exists(path):
             with open(path) as f:
                 manifest.update(json.load(f))
+        if manifest["format"] != 1:
+            raise ValueError("%s: manifest format %r is not supported (this package reads format 1)"
+                             % (path, manifest["format"]))
+        allowed = dict(_COMPONENTS)
+        if components:
+            if not hasattr(components, "items"):
+                components = {_import_path(k): k for k in components}
+            allowed.update(components)
         given = {"feat_ext": feat_ext, "projection": projection}
         for attr, fname in cls._component_files.items():
             if given[attr] is None and attr in manifest["components"]:
-                klass = _resolve(manifest["components"][attr])
-                given[attr] = klass.load_from_file(os.path.join(model_dir, fname))
+                name = manifest["components"][attr]
+                if name not in allowed:
+                    raise ValueError(
+                        "%s names %s class %r, which is not registered: decorate it with "
+                        "register_component, or pass components=[...] / %s= to load_from_dir"
+                        % (path, attr, name, attr))
+                given[attr] = allowed[name].load_from_file(os.path.join(model_dir, fname))
         if given["feat_ext"] is None:
             raise ValueError("%s names no feature extractor: pass feat_ext=" % model_dir)
         obj = cls.__new__(cls)
@@ -252,14 +281,6 @@ class BagOfWords(object):
 def _import_path(klass):
     return "%s:%s" % (klass.__module__, klass.__qualname__)
 
-
-def _resolve(path):
-    """'package.module:Class.Inner' -> the class object (importlib, no pickle)."""
-    module, _, qual = path.partition(":")
-    obj = importlib.import_module(module)
-    for part in qual.split("."):
-        obj = getattr(obj, part)
-    return obj
 
 
 class SpatialBagOfWords(BagOfWords):

@@ -39,6 +39,8 @@ def vq(obs, code_book, check_finite=True, backend=None):
     if obs_a.shape[1] != cb_a.shape[1]:
         raise ValueError("Code book(%d) and obs(%d) should have the same number of features "
                          "(e.g. columns)" % (cb_a.shape[1], obs_a.shape[1]))
+    if cb_a.shape[0] < 1 or cb_a.shape[1] < 1:
+        raise ValueError("empty codebook (shape %s)" % (cb_a.shape,))
     if obs_a.shape[1] > MAX_DIM:
         raise ValueError("vq: observations have %d features, this device search handles at most "
                          "%d (local image descriptors)" % (obs_a.shape[1], MAX_DIM))

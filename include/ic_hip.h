@@ -14,9 +14,11 @@
  *     a parameter is documented as "host".  The library never frees caller memory.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
  *     and return; the caller synchronises the stream before reading outputs.
- *   - a handle owns a grow-only device workspace (partial results, padded norms).  Growing it
- *     synchronises the device once; calls on one handle are serialised by a mutex, so a handle
- *     may be shared by threads.  Handles must not cross fork(): create one per process.
+ *   - a handle owns a grow-only device workspace (partial results, padded norms).  A call that
+ *     needs more than the handle holds first waits for the handle's own previous call (an event,
+ *     not a device synchronisation), then frees and reallocates; ic_reserve_workspace does that
+ *     up front.  Calls on one handle are serialised by a mutex, so a handle may be shared by
+ *     threads.  Handles must not cross fork(): create one per process.
  *   - descriptor dimension d: 1 <= d <= 128 (rows are zero-padded to 128 internally).  With
  *     d = 128 the descriptor-search entry points (ic_assign_*, ic_codebook_aux) read x and c in
  *     place, 16 bytes at a time: both must be 16-byte aligned (IC_EINVAL otherwise).

@@ -584,7 +584,21 @@ def test_codebook_fingerprint_sees_every_element():
     assert not _frozen(ro_view)                                # its base is still writable
     own = cb.copy()
     own.setflags(write=False)
-    assert _frozen(own) and _frozen(own[::2])
+    assert not _frozen(own)                 # can be thawed, edited and frozen again between calls
+    fixed = np.frombuffer(cb.tobytes(), dtype=cb.dtype).reshape(cb.shape)
+    assert _frozen(fixed) and _frozen(fixed[::2])              # bytes: nothing can write there
+    with pytest.raises(ValueError):
+        fixed.setflags(write=True)
+
+
+def test_empty_codebook_is_a_value_error(backend):
+    with pytest.raises(ValueError):
+        vq(np.zeros((3, 128), np.float32), np.zeros((0, 128)), backend=backend)
+    from image_classification_amd import device
+    import torch
+    for shape in ((0, 128), (4, 0)):
+        with pytest.raises(ValueError, match="empty codebook"):
+            device.resident(np.zeros(shape), torch.device("cpu"))
 
 
 @pytest.mark.gpu
@@ -601,19 +615,24 @@ def test_codebook_edited_in_place_between_calls_is_seen():
     code1, dist1 = vq(obs, cb)
     assert code1[0] == target and dist1[0] == 0.0
     assert np.array_equal(code1[1:], code0[1:]) or np.mean(code1[1:] == code0[1:]) > 0.99
-    # a frozen vocabulary is recognised without hashing; thawed and edited, it is hashed again
+    # a vocabulary over immutable memory is recognised without hashing
     from image_classification_amd import device
-    cb.setflags(write=False)
-    code2, _ = vq(obs, cb)
+    fixed = np.frombuffer(cb.tobytes(), dtype=cb.dtype).reshape(cb.shape)
+    code2, _ = vq(obs, fixed)
     assert np.array_equal(code2, code1)
-    hits = dict(device._frozen_hits)
-    assert any(v[0]() is cb for v in hits.values())
-    code3, _ = vq(obs, cb)
+    assert any(v[0]() is fixed for v in device._frozen_hits.values())
+    code3, _ = vq(obs, fixed)
     assert np.array_equal(code3, code1)
+    # an owning array that is frozen, used, thawed, edited and frozen again is hashed every time
+    cb.setflags(write=False)
+    code4, _ = vq(obs, cb)
+    assert np.array_equal(code4, code1)
+    assert not any(v[0]() is cb for v in device._frozen_hits.values())
     cb.setflags(write=True)
     cb[target] = 0.0
-    code4, _ = vq(obs, cb)
-    assert code4[0] != target
+    cb.setflags(write=False)
+    code5, _ = vq(obs, cb)
+    assert code5[0] != target
 
 
 class _SavableExtractor(object):
@@ -647,11 +666,22 @@ def test_bag_of_words_model_directory_round_trip(backend, tmp_path):
     d = str(tmp_path / "bow")
     bow.save_to_dir(d)
     assert sorted(os.listdir(d)) == ["bow.json", "feat_ext", "vocab.npy"]
-    back = BagOfWords.load_from_dir(d, backend=backend)
+    # the manifest can only name classes the program has registered or handed over
+    with pytest.raises(ValueError, match="not registered"):
+        BagOfWords.load_from_dir(d, backend=backend)
+    back = BagOfWords.load_from_dir(d, backend=backend, components=[_SavableExtractor])
     assert isinstance(back.feat_ext, _SavableExtractor) and back.norm == "l2"
     assert np.array_equal(back.vocab, vocab) and back.vocabsize == 12
     assert np.array_equal(back.extract([1, 2])[1], bow.extract([1, 2])[1])
     # a directory that holds only the reference's vocab.npy: the caller supplies the extractor
+    import json
+    with open(os.path.join(d, "bow.json")) as f:
+        man = json.load(f)
+    man["format"] = 2
+    with open(os.path.join(d, "bow.json"), "w") as f:
+        json.dump(man, f)
+    with pytest.raises(ValueError, match="format"):
+        BagOfWords.load_from_dir(d, backend=backend, components=[_SavableExtractor])
     os.unlink(os.path.join(d, "bow.json"))
     with pytest.raises(ValueError):
         BagOfWords.load_from_dir(d, backend=backend)
@@ -660,6 +690,8 @@ def test_bag_of_words_model_directory_round_trip(backend, tmp_path):
     # subclass parameters travel in the manifest
     sbow = SpatialBagOfWords(2, 40, 60, _SavableExtractor(), vocab=vocab, backend=backend)
     sbow.save_to_dir(str(tmp_path / "sbow"))
+    from image_classification_amd.features import register_component
+    register_component(_SavableExtractor)
     sback = SpatialBagOfWords.load_from_dir(str(tmp_path / "sbow"), backend=backend)
     assert (sback.n_levels, sback.im_height, sback.im_width) == (2, 40, 60)
     assert isinstance(sback, SpatialBagOfWords)
