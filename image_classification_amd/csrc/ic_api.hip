@@ -159,8 +159,8 @@ int profile_open(Ctx* c, hipStream_t s, hipEvent_t* stop) {
 // Launch sequence: [pad rows and codebook to 128 columns] -> [auxiliary block of the codebook,
 // unless the caller brought one] -> [hint thresholds] -> matrix-core search (best, second best and
 // the value of the third per row and K-split) -> k_rescore (merge, direct evaluation of the pair,
-// outputs, flags) + list of flagged rows -> direct search of the flagged rows, overwriting their
-// outputs.  The number of flagged rows never reaches the host.
+// outputs, list of the rows it cannot decide) -> direct search of the listed rows, overwriting
+// their outputs.  The number of flagged rows never reaches the host.
 int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                 const float* c_aux, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
                 uint8_t* mask, ic_top2_rec* rec, void* stream, const char* who,
@@ -191,17 +191,15 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   ic::assign_plan(n, k, ctx->num_cus, &plan);
   const bool pad = d != ic::kD;
   const size_t records = (size_t)ic::assign_part_records(plan, n);
-  const int64_t rs_grid = (n + ic::rescore_chunk(n) - 1) / ic::rescore_chunk(n);
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
   const size_t o_aux = c_aux ? 0 : take((size_t)(ic::kAuxNorms + kpad) * 4);
   const size_t o_auxs = c_aux ? 0 : take(ic::codebook_aux_scratch_bytes(k));
   const size_t o_part = take(records * sizeof(ic_top2_rec));
   const size_t o_part3 = take(records * 4);
-  const size_t o_flags = take((size_t)n);
-  const size_t o_cnt = take((size_t)rs_grid * 4);
   const size_t o_list = take((size_t)n * 4);
   const size_t o_count = take(4);
+  const size_t o_tickets = take((size_t)ic::kExactGrid * 4);
   const size_t o_expart = take((size_t)ic::kExactGrid * 16 * sizeof(ic_top2_rec));
   const size_t o_xp = pad ? take((size_t)n * ic::kD * 4) : 0;
   const size_t o_cp = pad ? take((size_t)k * ic::kD * 4) : 0;
@@ -256,18 +254,19 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     if (rc) return rc;
   }
   float* rowband = index_only ? reinterpret_cast<float*>(ws + o_band) : nullptr;
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, part, part3, rowband, s),
-         "distance/top-2 kernel");
-  if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   int32_t* list = reinterpret_cast<int32_t*>(ws + o_list);
   uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
-  IC_HIP(ic::launch_rescore(xs, n, cs, aux, part, part3, rowband, plan, mode2, i1, d1, i2, d2, ratio, mask,
-                            rec, reinterpret_cast<uint8_t*>(ws + o_flags),
-                            reinterpret_cast<uint32_t*>(ws + o_cnt), list, count, s),
-         "rescore kernels");
+  uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + o_tickets);
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, part, part3, rowband, count,
+                                 s),
+         "distance/top-2 kernel");
+  if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, part, part3, rowband, plan, mode2, i1, d1, i2, d2,
+                            ratio, mask, rec, list, count, tickets, s),
+         "rescore kernel");
   IC_HIP(ic::launch_exact_rows(xs, n, cs, k, list, count,
-                               reinterpret_cast<ic_top2_rec*>(ws + o_expart), i1, d1, i2, d2,
-                               ratio, mask, rec, s),
+                               reinterpret_cast<ic_top2_rec*>(ws + o_expart), tickets, i1, d1, i2,
+                               d2, ratio, mask, rec, s),
          "direct search of the flagged rows");
   if (ctx->debug_count) {   // ic_debug_flagged: how many rows took the second look
     IC_HIP(hipMemcpyAsync(ctx->debug_count, count, 4, hipMemcpyDeviceToDevice, s),

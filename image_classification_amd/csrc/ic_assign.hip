@@ -22,8 +22,11 @@
 //     buffers; rows are padded to 528 bytes (through the SOURCE address: the LDS image of such a
 //     load is lane-linear) so that ds_read_b128 is bank-conflict free with immediate offsets.
 //   * grid = the row tiles that fill whole rounds of the machine, each scanning the entire
-//     codebook, followed by (row tile, K-split) pairs for the last, partly filled round; every
-//     workgroup writes one (value, index) x 2 record per row, k_rescore merges the splits.
+//     codebook, followed by the workgroups of the last, partly filled round: those walk equal
+//     shares of the linearised (row tile, stage) space of the remaining row tiles, crossing from
+//     the end of one row tile into the start of the next, so every CU gets the same amount of
+//     work whatever the number of row tiles; every piece of a row tile writes one
+//     (value, index) x 2 record per row and lane half, k_rescore merges the pieces.
 //   * ranking is gated twice (tile minimum, then per register) because on gfx950 the fp32 MFMA
 //     and the vector ALU never co-execute: every ranking instruction costs MFMA time.
 //
@@ -80,45 +83,16 @@ struct Stage {
 constexpr int kXT = 1;
 constexpr int kSmallCodebook = 8192;   // below this: two 8-wave workgroups per CU
 
-// K-split that finishes `row_tiles` row tiles soonest, in units of one stage of work.
-//
-// One 16-wave workgroup per CU (large codebooks): workgroups run in rounds of `slots`, each
-// paying its row-tile load and pipeline fill in the open (about two stages' worth).
-//
-// Two 8-wave workgroups per CU: the matrix pipe is shared, so a CU's time is the work it is
-// given, a workgroup's start-up hides behind its neighbour's multiplies (about 0.6 of a stage
-// stays visible, mostly the reload of the row tile), and workgroups start as others finish, so
-// the machine drains within about one item of the ideal.  Measured on 100 000 x 1000 (391 row
-// tiles on 512 slots): unsplit 0.297 ms, 4 pieces 0.281, 6 pieces 0.263, 16 pieces 0.362.
-static int choose_nsplit(int64_t row_tiles, int64_t stages, int slots, bool two_per_cu) {
-  int best = 1;
-  double best_cost = 1e300;
-  const int64_t max_ns = stages < 256 ? stages : 256;
-  for (int64_t ns = 1; ns <= max_ns; ++ns) {
-    const int64_t longest = (stages + ns - 1) / ns;   // pieces differ by at most one stage
-    double cost;
-    if (two_per_cu) {
-      if (longest < 2 && stages >= 2) continue;       // one-stage pieces only reload row tiles
-      const double ovh = 0.6;
-      const double work = (double)row_tiles * ((double)stages + (double)ns * ovh);
-      cost = work / (0.5 * slots) + 0.7 * ((double)longest + ovh);
-    } else {
-      const double ovh = 2.0;
-      const int64_t rounds = (row_tiles * ns + slots - 1) / slots;
-      cost = (double)rounds * ((double)longest + ovh) * (1.0 + 0.002 * (double)ns);
-    }
-    if (cost < best_cost * 0.999) {
-      best_cost = cost;
-      best = (int)ns;
-    }
-  }
-  return best;
-}
-
 // Row tiles that fill whole rounds of the machine are searched over the entire codebook by one
 // workgroup each (the longer a lane's scan, the rarer a tile improves its top-2, so ranking gets
-// cheaper, and X is read once); only the row tiles of the last, partly filled round are split
-// along K so that their pieces spread over all CUs.
+// cheaper, and X is read once).  The row tiles of the last, partly filled round would leave CUs
+// idle (391 row tiles on 512 workgroup slots) or, cut into equal K-pieces, cost a row-tile load
+// and a pipeline fill per piece (six pieces per row tile were the best such cut for 100 000 x
+// 1000, at 60 % of peak).  Instead the (row tile, stage) pairs of those row tiles are laid out in
+// one line, tile after tile, and cut into `tail_wgs` runs of `tail_quota` stages: workgroup g of
+// the tail takes run g, which may end one row tile and begin the next.  Every workgroup then has
+// the same amount of matrix work, a row tile is loaded by at most max_pieces workgroups, and the
+// codebook stages keep streaming through LDS across the change of row tile.
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
   // IC_AMD_GEOMETRY forces a shape (1 = two 8-wave workgroups per CU, 2 = one of 16; tuning aid)
   static const int geom = [] {
@@ -126,31 +100,38 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
     return v ? atoi(v) : 0;
   }();
   const bool small = geom == 1 || (geom != 2 && k < kSmallCodebook);
+  p->num_cus = num_cus;
   p->waves = small ? 8 : 16;
   p->stage_k = small ? 64 : 128;
   p->rows_per_wg = kXT * p->waves * 32;
   const int slots = num_cus * (small ? 2 : 1);  // workgroups resident at once
   const int64_t stages = (k + p->stage_k - 1) / p->stage_k;
+  p->stages = (int)stages;
   p->row_tiles = (n + p->rows_per_wg - 1) / p->rows_per_wg;
-  // IC_AMD_NSPLIT forces one split for every row tile (tuning aid)
+  // IC_AMD_QUOTA forces the tail decomposition on every row tile with that many stages per
+  // workgroup (tuning aid, and the tests' way to reach many pieces per row tile)
   static const int forced = [] {
-    const char* v = getenv("IC_AMD_NSPLIT");
+    const char* v = getenv("IC_AMD_QUOTA");
     return v ? atoi(v) : 0;
   }();
-  int ns;
-  if (forced > 0) {
-    p->full_tiles = 0;
-    ns = forced;
-  } else {
-    p->full_tiles = p->row_tiles / slots * slots;
-    const int64_t rem = p->row_tiles - p->full_tiles;
-    ns = rem > 0 ? choose_nsplit(rem, stages, slots, small) : 1;
-  }
-  if (ns > stages) ns = (int)stages;
-  if (ns < 1) ns = 1;
-  p->nsplit = ns;
-  p->split_base = (int)(stages / ns);     // piece sp covers split_base (+1 for sp < split_extra)
-  p->split_extra = (int)(stages % ns);    // stages, in order
+  p->full_tiles = forced > 0 ? 0 : p->row_tiles / slots * slots;
+  const int64_t tail = p->row_tiles - p->full_tiles;
+  p->tail_quota = (int)stages;
+  p->tail_wgs = tail;
+  p->max_pieces = 1;
+  if (tail == 0) return;
+  // cutting pays when the idle slots of the round are worth more than the extra row-tile loads
+  // (about two stages' time per workgroup)
+  if (forced <= 0 && (slots - tail) * stages <= 2 * (int64_t)slots) return;
+  const int64_t units = tail * stages;
+  int64_t q = forced > 0 ? forced : (units + slots - 1) / slots;
+  const int64_t q_min = stages < 2 ? stages : 2;   // one-stage runs only reload row tiles
+  if (q < q_min) q = q_min;
+  if (q > stages) q = stages;                      // (only when forced)
+  p->tail_quota = (int)q;
+  p->tail_wgs = (units + q - 1) / q;
+  const int64_t pieces = (stages - 1) / q + 2;     // runs a row tile's stages can fall into
+  p->max_pieces = (int)(pieces < stages ? pieces : stages);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,164 +363,278 @@ __device__ __forceinline__ void tile_epilogue_all(const f32x16 (&acc)[XT], Top2 
   }
 }
 
-// Slot of row r's record in list l = 2 * (K-split) + (lane half).  The two lanes that hold a
-// descriptor rank disjoint halves of every tile's codewords and each writes its own record: kept
-// apart, the halves are two more places where k_rescore can find the INDEX of a candidate inside
-// the error band, which quarters the rows that need the second look.  Lists 0 and 1 exist for
-// every row ([2][N] records); only the rows from split_row0 on (the last, partly filled round of
-// row tiles) have further lists, stored behind as [2 nsplit - 2][N - split_row0].
+// Slot of row r's record in list l = 2 * (piece of its row tile) + (lane half).  The two lanes
+// that hold a descriptor rank disjoint halves of every tile's codewords and each writes its own
+// record: kept apart, the halves are two more places where k_rescore can find the INDEX of a
+// candidate inside the error band, which quarters the rows that need the second look.  Lists 0
+// and 1 exist for every row ([2][N] records); only the rows from split_row0 on (the last, partly
+// filled round of row tiles) can have further lists, stored behind as
+// [2 max_pieces - 2][N - split_row0].
 __device__ __forceinline__ int64_t part_slot(int l, int64_t r, int64_t N, int64_t split_row0) {
   return l < 2 ? (int64_t)l * N + r : 2 * N + (int64_t)(l - 2) * (N - split_row0) + (r - split_row0);
 }
 
+// The tail of the grid: tail row tile tt (counted from the first row tile of the tail) owns the
+// units [tt S, (tt + 1) S) of the line of (row tile, stage) pairs, workgroup g of the tail the
+// units [g q, (g + 1) q).  The pieces of a row tile are the runs its units fall into, numbered
+// from the first such run.
+struct TailGeom {
+  int stages;        // S
+  int quota;         // q
+  int rows_per_wg;
+};
+__host__ __device__ __forceinline__ int tail_first_run(const TailGeom& t, int64_t tt) {
+  return (int)(tt * t.stages / t.quota);
+}
+__host__ __device__ __forceinline__ int tail_pieces(const TailGeom& t, int64_t tt) {
+  return (int)(((tt + 1) * t.stages - 1) / t.quota) - tail_first_run(t, tt) + 1;
+}
+
+#ifdef IC_TRACE
+// Timeline instrumentation of the search kernel (tools/wgtrace.py; built as a separate library by
+// `make trace`, never part of libic_hip.so): per workgroup the 100 MHz wall clock at entry, at the
+// first barrier, at the first change of row tile (before / after) and at exit, and where it ran.
+constexpr int kTraceWgs = 1 << 16;
+__device__ unsigned long long ic_trace_buf[kTraceWgs][8];
+#define IC_TRACE_PUT(slot, value)                                                         \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) ic_trace_buf[blockIdx.x][slot] = (value); \
+  } while (0)
+#define IC_TRACE_NOW(slot) IC_TRACE_PUT(slot, wall_clock64())
+#else
+#define IC_TRACE_PUT(slot, value) do {} while (0)
+#define IC_TRACE_NOW(slot) do {} while (0)
+#endif
+
 // aux: the codebook's auxiliary block (see AuxLayout in ic_internal.h): mean vector, the two
 // maxima of the rounding model, then the centred squared norms (+inf in the padding).
+//
+// A workgroup walks `left` consecutive units of the line of (row tile, stage) pairs, starting at
+// (tile, st): the first full_tiles workgroups one whole row tile each, the others a run of the
+// tail.  The codebook stages stream through the two LDS buffers without regard to row tiles (the
+// stage after the last one is stage 0 again); when the walk crosses into the next row tile the
+// waves store their lists, load the new rows into the same registers and go on.
 template <int XT, int NW, int SK, bool GATED, bool MODE2>
-__global__ __launch_bounds__(NW * 64) void k_top2_partial(
+__global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
-    const float* __restrict__ aux, int stages_total, int split_base, int split_extra,
-    int full_tiles, int split_tiles, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
-    float* __restrict__ part3, float* __restrict__ rowband) {
+    const float* __restrict__ aux, int stages_total, int full_tiles, int64_t tail_units,
+    int tail_quota, int last_round_from, const float* __restrict__ thr,
+    ic_top2_rec* __restrict__ part, float* __restrict__ part3, float* __restrict__ rowband,
+    uint32_t* __restrict__ zero_word) {
+  static_assert(XT == 1, "one 32-descriptor tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31;  // descriptor (B column / result column) and codeword row (A row)
   const int h = lane >> 5;  // which half of the 128 components this lane multiplies
   const float* __restrict__ cnp = aux + kAuxNorms;
+  // the search is the first kernel of a call: it clears the flagged-row counter k_rescore adds to
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
+  IC_TRACE_NOW(0);
+  IC_TRACE_PUT(3, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) |
+                      (unsigned)__builtin_amdgcn_s_getreg(63492));
+  IC_TRACE_PUT(4, 0ull);
+  IC_TRACE_PUT(5, 0ull);
+  IC_TRACE_PUT(6, (unsigned long long)clock64());
 
-  // the first full_tiles workgroups scan the whole codebook; the rest are (row tile, K-split) pairs
-  int rt = blockIdx.x, sp = 0, st0 = 0, st1 = stages_total;
+  // where this workgroup's walk begins, how many units it has, and which piece of its first row
+  // tile that is (a row tile entered at stage 0 is always piece 0)
+  int64_t tile = blockIdx.x;
+  int st = 0, left = stages_total, piece = 0;
   if ((int)blockIdx.x >= full_tiles) {
-    const int idx = (int)blockIdx.x - full_tiles;
-    rt = full_tiles + idx % split_tiles;
-    sp = idx / split_tiles;
-    st0 = sp * split_base + (sp < split_extra ? sp : split_extra);
-    st1 = st0 + split_base + (sp < split_extra ? 1 : 0);
+    const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
+    const int64_t tt = u / stages_total;
+    const int64_t rest = tail_units - u;
+    tile = full_tiles + tt;
+    st = (int)(u - tt * stages_total);
+    left = rest < tail_quota ? (int)rest : tail_quota;
+    piece = ((int)blockIdx.x - full_tiles) - (int)(tt * stages_total / tail_quota);
   }
+  const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
+  // Workgroups of the grid's last round are followed by nothing.  The SIMDs serve the oldest
+  // wave first, so of two workgroups that share a CU the older one finishes early and the other
+  // runs its second half alone, two waves per SIMD, with the matrix pipe idle a quarter of the
+  // time.  In the last round a workgroup therefore lowers its priority as it progresses (3 in
+  // its first quarter ... 0 in its last): whoever is behind is served first, and the two finish
+  // within a quarter of each other.  Earlier rounds keep oldest-first, which is what staggers
+  // the workgroups of a CU so that one's start-up hides behind the other's multiplies.
+  const bool paced = (int)blockIdx.x >= last_round_from;
+  const int total_units = left;
+  int prio_now = -1;
 
   // The codebook mean travels through a slot of LDS private to the wave (512 bytes behind the
   // stage buffers): its load is the first one issued, so it has landed long before the rows, and
   // nothing issued after the stage loads has to be waited for before the first MFMA.
+  // It goes global -> LDS directly (lanes 0..31 carry its 512 bytes), through no register.
   float* mu_lds = reinterpret_cast<float*>(smem + 2 * Stage<SK>::kBytes) + wave * kD;
-  f32x4 mu_in = {0.f, 0.f, 0.f, 0.f};
-  if (lane < 32) mu_in = reinterpret_cast<const f32x4*>(aux)[lane];
+  if (lane < 32) glds16(aux + lane * 4, reinterpret_cast<char*>(mu_lds));
 
-  // descriptors of this wave, 64 components per lane.  Their loads go out next, then the first
-  // two stages of the codebook.
-  const int64_t row0 = (int64_t)rt * (XT * NW * 32) + (int64_t)wave * (XT * 32);
-  f32x4 xv[XT][16];
+  int sti = st;            // codebook stage of the next unit to issue
+  int to_issue = left;     // units whose stage has not been issued yet
+  auto issue_next = [&](char* sb) {
+    issue_stage<NW, SK>(C, K, cnp, sti, sb, wave, lane);
+    sti = sti + 1 == stages_total ? 0 : sti + 1;
+    --to_issue;
+  };
+  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  int buf = 0;
+  bool first = true;
+  for (;;) {
+    // descriptors of this wave, 64 components per lane
+    f32x4 xv[16];
+    {
+      int64_t r = tile * (NW * 32) + wave * 32 + j;
+      r = r < N ? r : N - 1;
+      const f32x4* p = reinterpret_cast<const f32x4*>(X + r * kD + h * 4);
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    int64_t r = row0 + xt * 32 + j;
-    r = r < N ? r : N - 1;
-    const f32x4* p = reinterpret_cast<const f32x4*>(X + r * kD + h * 4);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) xv[xt][q] = p[2 * q];
-  }
-  if (lane < 32) reinterpret_cast<f32x4*>(mu_lds)[lane] = mu_in;
-  issue_stage<NW, SK>(C, K, cnp, st0, smem, wave, lane);
-  const bool two = st0 + 1 < st1;
-  if (two) issue_stage<NW, SK>(C, K, cnp, st0 + 1, smem + Stage<SK>::kBytes, wave, lane);
-
-  // centre the rows on the codebook mean and scale by -2 (exact); on the way, this lane's half of
-  // |x - m|^2 and of (x - m).m for the band
-  float xr[XT][64];
-  float c0[XT];
-  {
-    const f32x4* mp = reinterpret_cast<const f32x4*>(mu_lds + h * 4);
-#pragma unroll
-    for (int xt = 0; xt < XT; ++xt) {
+      for (int q = 0; q < 16; ++q) xv[q] = p[2 * q];
+    }
+    // loads return in order.  First row tile: rows, then the two stages (at least kMinLoads loads
+    // per wave and stage): the rows are complete once at most that many loads as were issued
+    // behind them are outstanding, and centring them overlaps the stages' flight.  Later row
+    // tiles: the rows' loads are the last ones issued.
+    constexpr int kMinLoads = Stage<SK>::kGlds / NW;
+    bool two = false;
+    if (first) {
+      issue_next(smem);
+      two = to_issue > 0;
+      if (two) {
+        issue_next(smem + Stage<SK>::kBytes);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kMinLoads) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMinLoads) : "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // centre the rows on the codebook mean and scale by -2 (exact); on the way, this lane's half
+    // of |x - m|^2 and of (x - m).m for the band
+    float xr[1][64];
+    float c0[1];
+    {
+      // opaque offset: the mean is read from LDS again for every row tile instead of being kept
+      // in 64 registers across the sweep, which the MFMA operands need
+      int moff = h * 16;
+      asm volatile("" : "+v"(moff));
+      const f32x4* mp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(mu_lds) + moff);
       float xn = 0.f, xm = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const f32x4 mu = mp[2 * q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float t = xv[xt][q][e] - mu[e];
+          const float t = xv[q][e] - mu[e];
           xn = __builtin_fmaf(t, t, xn);
           xm = __builtin_fmaf(t, mu[e], xm);
-          xr[xt][q * 4 + e] = -2.0f * t;
+          xr[0][q * 4 + e] = -2.0f * t;
         }
       }
       xn += __shfl_xor(xn, 32);
       xm += __shfl_xor(xm, 32);
-      const float bound = error_bound(xn, aux[kAuxCnMax], aux[kAuxCr2Max]);
-      c0[xt] = 2.01f * bound + kBandSlope * (xn + 2.f * xm);
+      const float bound = error_bound(xn, cn_max, cr2_max);
+      c0[0] = 2.01f * bound + kBandSlope * (xn + 2.f * xm);
     }
-  }
-
-  Top2 best[XT];
-  float gate[XT];
-#pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    // with a caller-supplied bound only candidates below it are ranked at all (index -1 = none);
-    // the bound then stands for every candidate that was never looked at
-    float start = __builtin_inff();
-    if (thr) {
-      int64_t r = row0 + xt * 32 + j;
-      start = thr[r < N ? r : N - 1];
+    const int64_t row = tile * (NW * 32) + wave * 32 + j;
+    Top2 best[1];
+    float gate[1];
+    {
+      // with a caller-supplied bound only candidates below it are ranked at all (index -1 =
+      // none); the bound then stands for every candidate that was never looked at
+      float start = __builtin_inff();
+      if (thr) start = thr[row < N ? row : N - 1];
+      best[0].d1 = start;
+      best[0].d2 = start;
+      best[0].d3 = start;
+      best[0].i1 = -1;
+      best[0].i2 = -1;
+      gate[0] = start;
     }
-    best[xt].d1 = start;
-    best[xt].d2 = start;
-    best[xt].d3 = start;
-    best[xt].i1 = -1;
-    best[xt].i2 = -1;
-    gate[xt] = start;
-  }
 
-  // loads return in order: with the second stage in flight (at least 8 loads per wave, issued
-  // last) the rows and the first stage are complete once at most 8 loads are outstanding
-  constexpr int kMinLoads = Stage<SK>::kGlds / NW;
-  if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMinLoads) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+    if (first) {
+      // the first stage has landed once at most the second one's loads are outstanding
+      if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMinLoads) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      first = false;
+      IC_TRACE_NOW(1);
+    } else {
+      IC_TRACE_NOW(5);
+    }
 
-  f32x16 acc[XT];
-  for (int st = st0; st < st1; ++st) {
-    char* sb = smem + ((st - st0) & 1) * Stage<SK>::kBytes;
-#pragma unroll
-    for (int t = 0; t < Stage<SK>::kTiles; ++t) {
-      // tiles that lie wholly past the end of the codebook (padding of the last stage) are skipped
-      const bool live = (st * Stage<SK>::kTiles + t) * kTileK < K;
-      if (live)
-        compute_tile<XT>(sb + t * kTileK * kRowBytes, sb + Stage<SK>::kTileBytes + t * kTileK * 4, xr,
-                         acc, j, h);
-      if (t == Stage<SK>::kTiles - 1) {
-        // every wave is done reading this buffer once it passes the barrier; the stage issued one
-        // iteration ago has landed in the other buffer by then
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 2 < st1) issue_stage<NW, SK>(C, K, cnp, st + 2, sb, wave, lane);
+    // this row tile's stages [st, st + item)
+    const int item = stages_total - st < left ? stages_total - st : left;
+    f32x16 acc[1];
+    for (int i = 0; i < item; ++i, ++st) {
+      char* sb = smem + buf * Stage<SK>::kBytes;
+      if (paced) {
+        const int want = (4 * (left - i) - 1) / total_units;   // 3, 2, 1, 0 by quarter remaining
+        if (want != prio_now) {
+          prio_now = want;
+          if (want >= 3) __builtin_amdgcn_s_setprio(3);
+          else if (want == 2) __builtin_amdgcn_s_setprio(2);
+          else if (want == 1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
       }
-      if (live) {
-        const int encbase = (st * Stage<SK>::kTiles + t) * 16;
-        if constexpr (GATED) tile_epilogue_gated<XT, MODE2>(acc, best, gate, c0, encbase);
-        else tile_epilogue_all<XT>(acc, best, encbase);
+#pragma unroll
+      for (int t = 0; t < Stage<SK>::kTiles; ++t) {
+        // tiles that lie wholly past the end of the codebook (padding of the last stage) are skipped
+        const bool live = (st * Stage<SK>::kTiles + t) * kTileK < K;
+        if (live)
+          compute_tile<1>(sb + t * kTileK * kRowBytes, sb + Stage<SK>::kTileBytes + t * kTileK * 4,
+                          xr, acc, j, h);
+        if (t == Stage<SK>::kTiles - 1) {
+          // every wave is done reading this buffer once it passes the barrier; the stage issued
+          // one iteration ago has landed in the other buffer by then
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (to_issue > 0) issue_next(sb);
+        }
+        if (live) {
+          const int encbase = (st * Stage<SK>::kTiles + t) * 16;
+          if constexpr (GATED) tile_epilogue_gated<1, MODE2>(acc, best, gate, c0, encbase);
+          else tile_epilogue_all<1>(acc, best, encbase);
+        }
+      }
+      buf ^= 1;
+    }
+    left -= item;
+
+    // decode (tile, register) -> codeword index and store this lane's list
+    {
+      const Top2& b = best[0];
+      auto decode = [h](int enc) {
+        if (enc < 0) return -1;
+        const int t = enc >> 4, r = enc & 15;
+        return t * kTileK + 8 * (r >> 2) + 4 * h + (r & 3);
+      };
+      if (row < N) {
+        ic_top2_rec rec;
+        rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
+        const int64_t slot = part_slot(2 * piece + h, row, N, split_row0);
+        part[slot] = rec;
+        part3[slot] = b.d3;
+        // the constant part of the row's band, for k_rescore's shortcut (same for every list)
+        if (rowband && piece == 0 && h == 0) rowband[row] = c0[0];
       }
     }
+    if (left <= 0) break;
+    // on into the next row tile
+    IC_TRACE_NOW(4);
+    ++tile;
+    st = 0;
+    piece = 0;
   }
-
-  // decode (tile, register) -> codeword index and store this lane's list
-#pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    const Top2& b = best[xt];
-    auto decode = [h](int enc) {
-      if (enc < 0) return -1;
-      const int t = enc >> 4, r = enc & 15;
-      return t * kTileK + 8 * (r >> 2) + 4 * h + (r & 3);
-    };
-    const int64_t r = row0 + xt * 32 + j;
-    if (r < N) {
-      ic_top2_rec rec;
-      rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
-      const int64_t slot = part_slot(2 * sp + h, r, N, (int64_t)full_tiles * (XT * NW * 32));
-      part[slot] = rec;
-      part3[slot] = b.d3;
-      // the constant part of the row's band, for k_rescore's shortcut (same for every list)
-      if (rowband && sp == 0 && h == 0) rowband[r] = c0[xt];
-    }
-  }
+  IC_TRACE_NOW(2);
+  IC_TRACE_PUT(7, (unsigned long long)clock64());
 }
+
+#ifdef IC_TRACE
+extern "C" int ic_trace_read(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ic_trace_buf), bytes, 0,
+                                  hipMemcpyDeviceToHost);
+}
+#endif
 
 // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
 // candidate, anything else (default) = the two-level gate.
@@ -555,18 +650,25 @@ template <int NW, int SK>
 static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
                                   const float* aux, const AssignPlan& plan, bool mode2,
                                   const float* thr, ic_top2_rec* part, float* part3,
-                                  float* rowband, hipStream_t s) {
+                                  float* rowband, uint32_t* zero_word, int num_cus,
+                                  hipStream_t s) {
   const int64_t stages = (k + SK - 1) / SK;
-  const int64_t split_tiles = plan.row_tiles - plan.full_tiles;
+  const int64_t tail_tiles = plan.row_tiles - plan.full_tiles;
   auto kern = !gated_variant() ? k_top2_partial<kXT, NW, SK, false, false>
               : mode2 ? k_top2_partial<kXT, NW, SK, true, true>
                       : k_top2_partial<kXT, NW, SK, true, false>;
   const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // allowed by assign_init() on this device
-  const int64_t grid = plan.full_tiles + split_tiles * plan.nsplit;
-  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int64_t grid = plan.full_tiles + plan.tail_wgs;
+  const int64_t slots = (int64_t)num_cus * (NW == 8 ? 2 : 1);
+  const int64_t last_round_from = grid > slots ? grid - slots : 0;
+  // the kernel's geometry must be the plan's: it indexes rows and records by it
+  if (stages != plan.stages || plan.rows_per_wg != NW * 32 || plan.tail_quota < 1 ||
+      plan.tail_wgs != (tail_tiles * stages + plan.tail_quota - 1) / plan.tail_quota)
+    return hipErrorInvalidValue;
+  if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
-                     (int)stages, plan.split_base, plan.split_extra, (int)plan.full_tiles,
-                     (int)split_tiles, thr, part, part3, rowband);
+                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota,
+                     (int)last_round_from, thr, part, part3, rowband, zero_word);
   return hipGetLastError();
 }
 
@@ -594,17 +696,19 @@ hipError_t assign_init() {
 int64_t assign_part_records(const AssignPlan& p, int64_t n) {
   int64_t split_row0 = p.full_tiles * (int64_t)p.rows_per_wg;
   if (split_row0 > n) split_row0 = n;
-  return 2 * n + (int64_t)(2 * p.nsplit - 2) * (n - split_row0);   // see part_slot
+  return 2 * n + (int64_t)(2 * p.max_pieces - 2) * (n - split_row0);   // see part_slot
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const AssignPlan& plan, bool mode2,
                                const float* thr, ic_top2_rec* part, float* part3, float* rowband,
-                               hipStream_t s) {
+                               uint32_t* zero_word, hipStream_t s) {
   if (plan.waves == 8 && plan.stage_k == 64)
-    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband, s);
+    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband,
+                                  zero_word, plan.num_cus, s);
   if (plan.waves == 16 && plan.stage_k == 128)
-    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband, s);
+    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband,
+                                    zero_word, plan.num_cus, s);
   return hipErrorInvalidValue;
 }
 
@@ -689,10 +793,13 @@ __device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, floa
   }
 }
 
-// Workgroup b owns rows [b chunk, (b + 1) chunk): merges their K-splits, evaluates the two
-// candidates of every row by direct differences, writes the outputs, and decides per row whether
-// the pair is certain to hold the answer (flags[row] = 0) or the row must be searched again by
-// direct differences (1); cnt[b] = number of its flagged rows.
+// Workgroup b owns rows [b chunk, (b + 1) chunk): merges the pieces of their row tiles, evaluates
+// the two candidates of every row by direct differences, writes the outputs, and decides per row
+// whether the pair is certain to hold the answer or the row must be searched again by direct
+// differences; such rows are appended to `list` (one atomic increment of *count per flagged row:
+// they are rare, their order in the list does not matter -- every row's second look is
+// independent and writes only that row's outputs -- and *count was cleared by the search kernel).
+// Workgroup 0 also clears the tickets of the second look.
 //
 // When only the index of the nearest codeword is wanted (rowband != NULL: the constant part of
 // each row's band, left by the search kernel), a first pass with one thread per row settles
@@ -704,11 +811,11 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
                                                  const float* __restrict__ aux,
                                                  const ic_top2_rec* __restrict__ part,
                                                  const float* __restrict__ part3,
-                                                 const float* __restrict__ rowband, int nsplit,
+                                                 const float* __restrict__ rowband, TailGeom tail,
                                                  int64_t split_row0, int mode2, int64_t chunk,
-                                                 FinalOut out, uint8_t* __restrict__ flags,
-                                                 uint32_t* __restrict__ cnt) {
-  __shared__ int wcnt[16];
+                                                 FinalOut out, int32_t* __restrict__ list,
+                                                 uint32_t* __restrict__ count,
+                                                 uint32_t* __restrict__ tickets) {
   __shared__ int todo[256];
   __shared__ int ntodo;
   const int sub = threadIdx.x & 15;
@@ -718,13 +825,19 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   const f32x4 m0 = *reinterpret_cast<const f32x4*>(aux + sub * 8);
   const f32x4 m1 = *reinterpret_cast<const f32x4*>(aux + sub * 8 + 4);
   const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < kExactGrid; t += 256) tickets[t] = 0;
+  // lists of a row: the two lane halves of every piece of its row tile (rows below split_row0
+  // were searched whole)
+  auto n_lists = [&](int64_t row) {
+    return row >= split_row0 ? 2 * tail_pieces(tail, (row - split_row0) / tail.rows_per_wg) : 2;
+  };
 
-  // one row, by the 16 lanes of a group; returns whether the row needs the direct search
-  auto full_look = [&](int64_t row) -> bool {
+  // one row, by the 16 lanes of a group; a row that needs the direct search is put on the list
+  auto full_look = [&](int64_t row) {
     ic_top2_rec b = part[row];
     float v3 = part3[row];
-    // lists of this row: the two lane halves of every K-split (rows below split_row0 were not split)
-    const int ns = row >= split_row0 ? 2 * nsplit : 2;
+    const int ns = n_lists(row);
     // v3: third smallest value over all lists; u3: the smallest "third of one list", i.e. the
     // best candidate whose INDEX no record holds
     float u3 = v3;
@@ -785,14 +898,12 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     }
     if (sub == 0) {
       write_final(out, row, s1, a1, s2, a2);
-      flags[row] = unsure ? 1 : 0;
+      if (unsure) list[atomicAdd(count, 1u)] = (int32_t)row;
     }
-    return unsure;
   };
 
-  int nflag = 0;
   if (rowband == nullptr) {
-    for (int64_t row = row_begin + grp; row < row_end; row += 16) nflag += full_look(row) ? 1 : 0;
+    for (int64_t row = row_begin + grp; row < row_end; row += 16) full_look(row);
   } else {
     for (int64_t base = row_begin; base < row_end; base += 256) {   // uniform trip count
       if (threadIdx.x == 0) ntodo = 0;
@@ -800,7 +911,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       const int64_t row = base + threadIdx.x;
       if (row < row_end) {
         ic_top2_rec b = part[row];
-        const int ns = row >= split_row0 ? 2 * nsplit : 2;
+        const int ns = n_lists(row);
         for (int s = 1; s < ns; ++s) {
           const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
           top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
@@ -810,64 +921,20 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
         const float band = __builtin_fmaf(b.d1, kBandSlope, rowband[row]);
         if (b.i1 >= 0 && (b.d2 - b.d1) > band) {   // false on NaN
           out.i1[row] = b.i1;
-          flags[row] = 0;
         } else {
           todo[atomicAdd(&ntodo, 1)] = (int)threadIdx.x;   // any order: rows are independent
         }
       }
       __syncthreads();
       const int nt = ntodo;
-      for (int t = grp; t < nt; t += 16) nflag += full_look(base + todo[t]) ? 1 : 0;
+      for (int t = grp; t < nt; t += 16) full_look(base + todo[t]);
       __syncthreads();
     }
   }
-  if (sub == 0) wcnt[grp] = nflag;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int g = 0; g < 16; ++g) t += wcnt[g];
-    cnt[blockIdx.x] = (uint32_t)t;
-  }
-}
-
-// Flags -> ascending list of flagged rows.  Workgroup b takes `cpw` consecutive chunks of
-// k_rescore's decomposition and places their rows behind those of all chunks before them; the
-// last workgroup also stores the total.
-__global__ __launch_bounds__(256) void k_flag_scatter(const uint8_t* __restrict__ flags,
-                                                      const uint32_t* __restrict__ cnt, int64_t N,
-                                                      int64_t chunk, int cpw,
-                                                      int32_t* __restrict__ list,
-                                                      uint32_t* __restrict__ count) {
-  __shared__ uint32_t red[4];
-  __shared__ uint32_t wave_n[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t before = 0;
-  const unsigned first_chunk = blockIdx.x * (unsigned)cpw;
-  for (unsigned i = threadIdx.x; i < first_chunk; i += 256) before += cnt[i];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off);
-  if (lane == 0) red[wave] = before;
-  __syncthreads();
-  uint32_t pos = red[0] + red[1] + red[2] + red[3];
-  const int64_t row_begin = (int64_t)first_chunk * chunk;
-  const int64_t row_end = row_begin + chunk * cpw < N ? row_begin + chunk * cpw : N;
-  for (int64_t base = row_begin; base < row_end; base += 256) {   // uniform trip count
-    const int64_t row = base + threadIdx.x;
-    const bool f = row < row_end && flags[row] != 0;
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
-    __syncthreads();   // wave_n of the previous round has been read
-    if (lane == 0) wave_n[wave] = (uint32_t)__builtin_popcountll(bal);
-    __syncthreads();
-    uint32_t wbase = pos;
-    for (int w = 0; w < wave; ++w) wbase += wave_n[w];
-    if (f) list[wbase + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = (int32_t)row;
-    pos += wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
-  }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count = pos;
 }
 
 // Rows per workgroup of k_rescore: few, so that many independent gathers are in flight, but never
-// more than 16384 workgroups (their counts are summed by every workgroup of k_flag_scatter).
+// more than 16384 workgroups.
 int64_t rescore_chunk(int64_t n) {
   int64_t chunk = (n + 16383) / 16384;
   chunk = (chunk + 15) / 16 * 16;
@@ -876,23 +943,18 @@ int64_t rescore_chunk(int64_t n) {
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
                           const ic_top2_rec* part, const float* part3, const float* rowband,
-                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                          uint8_t* mask, ic_top2_rec* rec, uint8_t* flags, uint32_t* cnt,
-                          int32_t* list, uint32_t* count, hipStream_t s) {
+                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
+                          uint32_t* count, uint32_t* tickets, hipStream_t s) {
   const int64_t chunk = rescore_chunk(n);
   const int64_t grid = (n + chunk - 1) / chunk;
   if (grid < 1 || n >= 0x7fffffffLL) return hipErrorInvalidValue;
   // the shortcut answers with an index only
   if (rowband && (mode2 || d1 || !i1)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, part, part3,
-                     rowband, plan.nsplit, plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
-                     FinalOut{i1, d1, i2, d2, ratio, mask, rec}, flags, cnt);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  const int cpw = chunk >= 1024 ? 1 : (int)(1024 / chunk);
-  const int64_t sgrid = (grid + cpw - 1) / cpw;
-  hipLaunchKernelGGL(k_flag_scatter, dim3((unsigned)sgrid), dim3(256), 0, s, flags, cnt, n, chunk,
-                     cpw, list, count);
+                     rowband, TailGeom{plan.stages, plan.tail_quota, plan.rows_per_wg},
+                     plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
+                     FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);
   return hipGetLastError();
 }
 
@@ -964,12 +1026,14 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
 // fixed-size grid walk; the number of pieces per group is chosen ON THE DEVICE from the number of
 // rows (exact_pieces): a handful of flagged rows against a long codebook must not be one
 // workgroup's job, and many rows need no cutting at all.  With more than one piece the partial
-// top-2 of an item (squared distances) goes to `partial` [row][pieces] for k_exact_finish,
-// otherwise the outputs are written directly.  Every loop bound is uniform in the workgroup and
-// known when the kernel starts.
+// top-2 of an item (squared distances) goes to `partial` [row][pieces] and the workgroup draws a
+// ticket of its group: whoever draws the last one folds the group's pieces by (squared distance,
+// index) -- the same values a whole scan would have compared -- and writes the outputs; with one
+// piece the outputs are written directly.  Every loop bound is uniform in the workgroup and known
+// when the kernel starts; with an empty list every workgroup returns at once.
 constexpr int kExactRows = 16;
 
-// Pieces per group and codewords per piece, the same in k_exact_top2 and k_exact_finish.
+// Pieces per group and codewords per piece.
 __device__ __forceinline__ int exact_pieces(int64_t n_groups, int grid, int max_pieces, int K,
                                             int* k_per) {
   int64_t s = 1;
@@ -991,8 +1055,10 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
                                                     const uint32_t* __restrict__ count,
                                                     int max_pieces,
                                                     ic_top2_rec* __restrict__ partial,
+                                                    uint32_t* __restrict__ tickets,
                                                     FinalOut fin) {
   __shared__ __attribute__((aligned(16))) float xs[kExactRows][kD];
+  __shared__ uint32_t ticket;
   __shared__ float rd1[4][kExactRows], rd2[4][kExactRows];
   __shared__ int ri1[4][kExactRows], ri2[4][kExactRows];
   __shared__ int64_t rows[kExactRows];
@@ -1087,30 +1153,26 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
         }
       }
     }
-  }
-}
-
-// One thread per listed row: fold its pieces by (squared distance, index) -- the same values a
-// whole scan would have compared -- and write the row's outputs.  `search_grid` is the grid
-// k_exact_top2 ran with.
-__global__ __launch_bounds__(256) void k_exact_finish(const int32_t* __restrict__ list,
-                                                      const uint32_t* __restrict__ count,
-                                                      int search_grid, int max_pieces, int K,
-                                                      const ic_top2_rec* __restrict__ partial,
-                                                      FinalOut fin) {
-  const int64_t total = (int64_t)*count;
-  int k_per;
-  const int pieces = exact_pieces((total + kExactRows - 1) / kExactRows, search_grid, max_pieces,
-                                  K, &k_per);
-  if (pieces == 1) return;   // the search wrote the outputs itself
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total;
-       t += (int64_t)gridDim.x * 256) {
-    ic_top2_rec b = partial[t * pieces];
-    for (int s = 1; s < pieces; ++s) {
-      const ic_top2_rec o = partial[t * pieces + s];
-      top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
+    if (pieces > 1) {
+      // the records above must be visible device-wide before the ticket is drawn, and the last
+      // drawer must not read the others' records from a stale cache
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) ticket = atomicAdd(&tickets[g], 1u);
+      __syncthreads();
+      if (ticket == (uint32_t)pieces - 1u) {   // uniform in the workgroup
+        __threadfence();
+        const int64_t t = g * kExactRows + threadIdx.x;
+        if (threadIdx.x < kExactRows && t < total) {
+          const volatile ic_top2_rec* pr = partial + t * pieces;
+          float b1 = pr[0].d1, b2 = pr[0].d2;
+          int k1 = pr[0].i1, k2 = pr[0].i2;
+          for (int s = 1; s < pieces; ++s)
+            top2_merge_pairs(b1, k1, b2, k2, pr[s].d1, pr[s].i1, pr[s].d2, pr[s].i2);
+          write_final(fin, rows[threadIdx.x], b1, k1, b2, k2);
+        }
+      }
     }
-    write_final(fin, list[t], b.d1, b.i1, b.d2, b.i2);
   }
 }
 
@@ -1121,23 +1183,20 @@ hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t 
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_exact_top2, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, (int)k,
                      (const int32_t*)nullptr, (const uint32_t*)nullptr, 1, (ic_top2_rec*)nullptr,
-                     FinalOut{i1, d1, i2, d2, ratio, mask, nullptr});
+                     (uint32_t*)nullptr, FinalOut{i1, d1, i2, d2, ratio, mask, nullptr});
   return hipGetLastError();
 }
 
 // The second look at the flagged rows.  Their number is only known on the device, so the grid is
-// fixed (kExactGrid workgroups) and the kernels derive the decomposition from *count.
+// fixed (kExactGrid workgroups) and the kernel derives the decomposition from *count.  tickets
+// [kExactGrid] must be zero (k_rescore clears them).
 hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,
                              const int32_t* list, const uint32_t* count, ic_top2_rec* partial,
-                             int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                             uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
+                             uint32_t* tickets, int32_t* i1, float* d1, int32_t* i2, float* d2,
+                             float ratio, uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
   const FinalOut fin{i1, d1, i2, d2, ratio, mask, rec};
   hipLaunchKernelGGL(k_exact_top2, dim3(kExactGrid), dim3(256), 0, s, x, n, c, (int)k, list, count,
-                     kExactGrid, partial, fin);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_exact_finish, dim3(64), dim3(256), 0, s, list, count, kExactGrid,
-                     kExactGrid, (int)k, partial, fin);
+                     kExactGrid, partial, tickets, fin);
   return hipGetLastError();
 }
 

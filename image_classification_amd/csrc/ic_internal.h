@@ -18,16 +18,20 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 // ---- ic_assign.hip ---------------------------------------------------------------------------
 // Decomposition of one search.  Geometry: workgroups of `waves` waves hold rows_per_wg rows in
 // registers and stream the codebook through LDS in stages of stage_k codewords.  The first
-// full_tiles row tiles are scanned over the whole codebook by one workgroup each, the remaining
-// ones in nsplit K-splits whose lengths differ by at most one stage.
+// full_tiles row tiles are scanned over the whole codebook by one workgroup each.  The remaining
+// row tiles' (row tile, stage) pairs form one line, tile after tile, that tail_wgs workgroups
+// walk in runs of tail_quota stages; a row tile's stages then fall into at most max_pieces runs.
 struct AssignPlan {
+  int num_cus;                     // of the device the plan was made for
   int waves, stage_k, rows_per_wg;
+  int stages;                      // codebook stages
   int64_t row_tiles, full_tiles;
-  int nsplit, split_base, split_extra;
+  int tail_quota, max_pieces;
+  int64_t tail_wgs;
 };
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p);
 // records the partial buffer of a plan holds: two per row (one per lane half), plus
-// 2 nsplit - 2 more for every row of the K-split tail
+// 2 max_pieces - 2 more for every row of the tail
 int64_t assign_part_records(const AssignPlan& p, int64_t n);
 // once per device, with that device current: function attributes of the search kernels
 hipError_t assign_init();
@@ -49,31 +53,33 @@ hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipSt
 // part [assign_part_records]: per K-split (|c-m|^2 - 2 (x-m).c, index) best and second best;
 // part3 the value of the third best.  mode2: the caller wants the second neighbour too.
 // rowband (may be NULL) [n]: the constant part of each row's band, for launch_rescore's shortcut.
+// zero_word (may be NULL): a device word the kernel clears (the flagged-row counter).
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const AssignPlan& plan, bool mode2,
                                const float* thr, ic_top2_rec* part, float* part3, float* rowband,
-                               hipStream_t s);
+                               uint32_t* zero_word, hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
                                  const float* aux, const int32_t* hint, float* thr,
                                  hipStream_t s);
-// merge the K-splits, evaluate the two candidates as sum (x-c)^2, order, sqrt, ratio test; flag
-// the rows whose pair is not certain to hold the answer and list them (ascending) with their
-// number.  flags [n] u8, cnt [ceil(n / rescore_chunk(n))] u32, list [n] i32, count [1] u32.
+// merge the pieces, evaluate the two candidates as sum (x-c)^2, order, sqrt, ratio test; the
+// rows whose pair is not certain to hold the answer are appended to list [n] i32 (any order),
+// *count (cleared beforehand, see zero_word above) counts them; tickets [kExactGrid] u32 are
+// cleared for launch_exact_rows.
 // rowband != NULL (only i1 wanted, top-1): rows whose second-best value lies outside the band of
 // the best are answered from the records alone.
 int64_t rescore_chunk(int64_t n);
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
                           const ic_top2_rec* part, const float* part3, const float* rowband,
                           const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
-                          float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, uint8_t* flags,
-                          uint32_t* cnt, int32_t* list, uint32_t* count, hipStream_t s);
+                          float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
+                          uint32_t* count, uint32_t* tickets, hipStream_t s);
 // search the listed rows again by direct differences and overwrite their outputs.
-// partial: 16 * kExactGrid records.
+// partial: 16 * kExactGrid records; tickets [kExactGrid], zero on entry.
 hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,
                              const int32_t* list, const uint32_t* count, ic_top2_rec* partial,
-                             int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
-                             uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
+                             uint32_t* tickets, int32_t* i1, float* d1, int32_t* i2, float* d2,
+                             float ratio, uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
 hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t n,
                              const int64_t* shard_base_host, int64_t* i1, float* d1, int64_t* i2,
                              float* d2, float ratio, uint8_t* mask, hipStream_t s);

@@ -76,6 +76,16 @@ def test_rows_beyond_whole_machine_rounds_are_k_split():
     _check_top2(x, c)
 
 
+@pytest.mark.parametrize("n,k", [(70_000, 1000), (90_000, 500), (140_000, 300), (3000, 5000),
+                                 (100, 5000), (131_072 + 40_000, 2000)])
+def test_runs_that_cross_row_tiles_equal_the_direct_search(n, k):
+    # the row tiles of the last, partly filled round are walked in runs of equal length that end
+    # inside one row tile and go on in the next (70 000 x 1000: 274 row tiles x 16 stages in runs
+    # of 9; 140 000 x 300: 35 tail row tiles x 5 stages in runs of 2), or cut one row tile into
+    # many pieces (100 x 5000): every row must still get the direct search's answer
+    _same_as_direct(sift_like(n, n_modes=512, seed=n % 97), sift_like(k, n_modes=512, seed=k % 89))
+
+
 def test_ties_lowest_index_wins():
     # duplicated codewords and rounded (integer) data: exact ties; scipy/numpy keep the lowest index
     x = sift_like(1500, seed=5, rounded=True)

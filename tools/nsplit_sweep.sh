@@ -1,7 +1,7 @@
 #!/bin/bash
-# Kernel time of short scans under forced K-splits (tuning aid; results are identical for every split).
-cd ${GRAFT_REPO_ROOT:-.}
-for ns in 0 2 3 4 5 6 8; do
-  echo "== IC_AMD_NSPLIT=$ns"
-  IC_AMD_NSPLIT=$ns timeout -k 10 100 python tools/kbench.py 100000x1000 30000x1000 60000x2000 50000x4000 20000x500 || exit 1
+# Sweep of the tail quota (stages per workgroup of the last, partly filled round) on short scans.
+# IC_AMD_QUOTA applies the tail decomposition to every row tile.
+for q in 2 3 4 6 8 13 16; do
+  echo "== IC_AMD_QUOTA=$q"
+  IC_AMD_QUOTA=$q timeout -k 10 100 python tools/kbench.py 100000x1000 30000x1000 60000x2000 50000x4000 20000x500 || exit 1
 done
