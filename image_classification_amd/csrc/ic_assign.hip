@@ -100,7 +100,6 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
     return v ? atoi(v) : 0;
   }();
   const bool small = geom == 1 || (geom != 2 && k < kSmallCodebook);
-  p->num_cus = num_cus;
   p->waves = small ? 8 : 16;
   p->stage_k = small ? 64 : 128;
   p->rows_per_wg = kXT * p->waves * 32;
@@ -418,9 +417,8 @@ template <int XT, int NW, int SK, bool GATED, bool MODE2>
 __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ aux, int stages_total, int full_tiles, int64_t tail_units,
-    int tail_quota, int last_round_from, const float* __restrict__ thr,
-    ic_top2_rec* __restrict__ part, float* __restrict__ part3, float* __restrict__ rowband,
-    uint32_t* __restrict__ zero_word) {
+    int tail_quota, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
+    float* __restrict__ part3, float* __restrict__ rowband, uint32_t* __restrict__ zero_word) {
   static_assert(XT == 1, "one 32-descriptor tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -451,17 +449,6 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     piece = ((int)blockIdx.x - full_tiles) - (int)(tt * stages_total / tail_quota);
   }
   const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
-  // Workgroups of the grid's last round are followed by nothing.  The SIMDs serve the oldest
-  // wave first, so of two workgroups that share a CU the older one finishes early and the other
-  // runs its second half alone, two waves per SIMD, with the matrix pipe idle a quarter of the
-  // time.  In the last round a workgroup therefore lowers its priority as it progresses (3 in
-  // its first quarter ... 0 in its last): whoever is behind is served first, and the two finish
-  // within a quarter of each other.  Earlier rounds keep oldest-first, which is what staggers
-  // the workgroups of a CU so that one's start-up hides behind the other's multiplies.
-  const bool paced = (int)blockIdx.x >= last_round_from;
-  const int total_units = left;
-  int prio_now = -1;
-
   // The codebook mean travels through a slot of LDS private to the wave (512 bytes behind the
   // stage buffers): its load is the first one issued, so it has landed long before the rows, and
   // nothing issued after the stage loads has to be waited for before the first MFMA.
@@ -566,16 +553,6 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     f32x16 acc[1];
     for (int i = 0; i < item; ++i, ++st) {
       char* sb = smem + buf * Stage<SK>::kBytes;
-      if (paced) {
-        const int want = (4 * (left - i) - 1) / total_units;   // 3, 2, 1, 0 by quarter remaining
-        if (want != prio_now) {
-          prio_now = want;
-          if (want >= 3) __builtin_amdgcn_s_setprio(3);
-          else if (want == 2) __builtin_amdgcn_s_setprio(2);
-          else if (want == 1) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
-        }
-      }
 #pragma unroll
       for (int t = 0; t < Stage<SK>::kTiles; ++t) {
         // tiles that lie wholly past the end of the codebook (padding of the last stage) are skipped
@@ -650,8 +627,7 @@ template <int NW, int SK>
 static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
                                   const float* aux, const AssignPlan& plan, bool mode2,
                                   const float* thr, ic_top2_rec* part, float* part3,
-                                  float* rowband, uint32_t* zero_word, int num_cus,
-                                  hipStream_t s) {
+                                  float* rowband, uint32_t* zero_word, hipStream_t s) {
   const int64_t stages = (k + SK - 1) / SK;
   const int64_t tail_tiles = plan.row_tiles - plan.full_tiles;
   auto kern = !gated_variant() ? k_top2_partial<kXT, NW, SK, false, false>
@@ -659,16 +635,14 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
                       : k_top2_partial<kXT, NW, SK, true, false>;
   const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // allowed by assign_init() on this device
   const int64_t grid = plan.full_tiles + plan.tail_wgs;
-  const int64_t slots = (int64_t)num_cus * (NW == 8 ? 2 : 1);
-  const int64_t last_round_from = grid > slots ? grid - slots : 0;
   // the kernel's geometry must be the plan's: it indexes rows and records by it
   if (stages != plan.stages || plan.rows_per_wg != NW * 32 || plan.tail_quota < 1 ||
       plan.tail_wgs != (tail_tiles * stages + plan.tail_quota - 1) / plan.tail_quota)
     return hipErrorInvalidValue;
   if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
-                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota,
-                     (int)last_round_from, thr, part, part3, rowband, zero_word);
+                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota, thr,
+                     part, part3, rowband, zero_word);
   return hipGetLastError();
 }
 
@@ -705,10 +679,10 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
                                uint32_t* zero_word, hipStream_t s) {
   if (plan.waves == 8 && plan.stage_k == 64)
     return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband,
-                                  zero_word, plan.num_cus, s);
+                                  zero_word, s);
   if (plan.waves == 16 && plan.stage_k == 128)
     return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband,
-                                    zero_word, plan.num_cus, s);
+                                    zero_word, s);
   return hipErrorInvalidValue;
 }
 

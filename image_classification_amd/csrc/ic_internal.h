@@ -22,7 +22,6 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 // row tiles' (row tile, stage) pairs form one line, tile after tile, that tail_wgs workgroups
 // walk in runs of tail_quota stages; a row tile's stages then fall into at most max_pieces runs.
 struct AssignPlan {
-  int num_cus;                     // of the device the plan was made for
   int waves, stage_k, rows_per_wg;
   int stages;                      // codebook stages
   int64_t row_tiles, full_tiles;
