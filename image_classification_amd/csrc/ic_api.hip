@@ -197,6 +197,8 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   const size_t o_auxs = c_aux ? 0 : take(ic::codebook_aux_scratch_bytes(k));
   const size_t o_part = take(records * sizeof(ic_top2_rec));
   const size_t o_part3 = take(records * 4);
+  const size_t o_part3i = mode2 ? take(records * 4) : 0;
+  const size_t o_part4 = mode2 ? take(records * 4) : 0;
   const size_t o_list = take((size_t)n * 4);
   const size_t o_count = take(4);
   const size_t o_tickets = take((size_t)ic::kExactGrid * 4);
@@ -225,8 +227,10 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     ws = ctx->ws;
   }
 
-  ic_top2_rec* part = reinterpret_cast<ic_top2_rec*>(ws + o_part);
-  float* part3 = reinterpret_cast<float*>(ws + o_part3);
+  const ic::PartBufs pb{reinterpret_cast<ic_top2_rec*>(ws + o_part),
+                        reinterpret_cast<float*>(ws + o_part3),
+                        mode2 ? reinterpret_cast<int32_t*>(ws + o_part3i) : nullptr,
+                        mode2 ? reinterpret_cast<float*>(ws + o_part4) : nullptr};
   const float* xs = x;
   const float* cs = c;
   if (pad) {
@@ -257,11 +261,10 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   int32_t* list = reinterpret_cast<int32_t*>(ws + o_list);
   uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
   uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + o_tickets);
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, part, part3, rowband, count,
-                                 s),
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, pb, rowband, count, s),
          "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
-  IC_HIP(ic::launch_rescore(xs, n, cs, aux, part, part3, rowband, plan, mode2, i1, d1, i2, d2,
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, pb, rowband, plan, mode2, i1, d1, i2, d2,
                             ratio, mask, rec, list, count, tickets, s),
          "rescore kernel");
   IC_HIP(ic::launch_exact_rows(xs, n, cs, k, list, count,

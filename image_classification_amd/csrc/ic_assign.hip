@@ -181,6 +181,11 @@ __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
 struct Top2 {
   float d1, d2, d3;   // best, second best, and the VALUE of the third best
   int i1, i2;
+  // searches that want the second neighbour too (MODE2) also keep the third best's index and
+  // the VALUE of the fourth: three candidates within the band of the second in one list are
+  // then still resolved by k_rescore instead of sending the row to the direct search
+  float d4;
+  int i3;
 };
 
 // Rounding model.  The MFMA chain is a k-ordered float32 fma chain: starting from cn = |c - m|^2
@@ -221,6 +226,16 @@ __device__ __forceinline__ void top2_update(float& d1r, float& d2r, int& i1r, in
 // The same, also keeping the third smallest value seen (d1 <= d2 <= d3 on entry and on exit).
 __device__ __forceinline__ void top3_update(float& d1r, float& d2r, float& d3r, int& i1r, int& i2r,
                                             float v, int enc) {
+  d3r = __builtin_amdgcn_fmed3f(v, d2r, d3r);
+  top2_update(d1r, d2r, i1r, i2r, v, enc);
+}
+
+// The same with the third best's index and the fourth smallest value (d1 <= d2 <= d3 <= d4).
+__device__ __forceinline__ void top4_update(float& d1r, float& d2r, float& d3r, float& d4r,
+                                            int& i1r, int& i2r, int& i3r, float v, int enc) {
+  d4r = __builtin_amdgcn_fmed3f(v, d3r, d4r);
+  const int t = v < d3r ? enc : i3r;
+  i3r = v < d2r ? i2r : t;          // a new best or second best pushes the old second to third
   d3r = __builtin_amdgcn_fmed3f(v, d2r, d3r);
   top2_update(d1r, d2r, i1r, i2r, v, enc);
 }
@@ -332,19 +347,26 @@ __device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top
     if (__builtin_amdgcn_ballot_w64(m < gate[xt]) != 0) {
       // rank inside the tile with the register number (an inline constant) as index; -1 / -2
       // stand for "the previous best / second best", resolved once after the 16 updates
-      float d1 = st[xt].d1, d2 = st[xt].d2, d3 = st[xt].d3;
+      float d1 = st[xt].d1, d2 = st[xt].d2, d3 = st[xt].d3, d4 = st[xt].d4;
       const float g = gate[xt];
-      int l1 = -1, l2 = -2;
+      int l1 = -1, l2 = -2, l3 = -3;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0))
-          top3_update(d1, d2, d3, l1, l2, a[r], r);   // lanes that did not pass: needless, never wrong
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
+          // lanes that did not pass: needless, never wrong
+          if constexpr (MODE2) top4_update(d1, d2, d3, d4, l1, l2, l3, a[r], r);
+          else top3_update(d1, d2, d3, l1, l2, a[r], r);
+        }
       const int o1 = st[xt].i1, o2 = st[xt].i2;
       st[xt].d1 = d1;
       st[xt].d2 = d2;
       st[xt].d3 = d3;
       st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
       st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
+      if constexpr (MODE2) {
+        st[xt].d4 = d4;
+        st[xt].i3 = l3 >= 0 ? encbase + l3 : (l3 == -1 ? o1 : (l3 == -2 ? o2 : st[xt].i3));
+      }
       gate[xt] = __builtin_fmaf(MODE2 ? d2 : d1, 1.f + kBandSlope, c0[xt]);
     }
   }
@@ -358,7 +380,8 @@ __device__ __forceinline__ void tile_epilogue_all(const f32x16 (&acc)[XT], Top2 
   for (int xt = 0; xt < XT; ++xt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      top3_update(st[xt].d1, st[xt].d2, st[xt].d3, st[xt].i1, st[xt].i2, acc[xt][r], encbase + r);
+      top4_update(st[xt].d1, st[xt].d2, st[xt].d3, st[xt].d4, st[xt].i1, st[xt].i2, st[xt].i3,
+                  acc[xt][r], encbase + r);
   }
 }
 
@@ -407,6 +430,7 @@ __device__ unsigned long long ic_trace_buf[kTraceWgs][8];
 
 // aux: the codebook's auxiliary block (see AuxLayout in ic_internal.h): mean vector, the two
 // maxima of the rounding model, then the centred squared norms (+inf in the padding).
+// pb: where the lists go (rec / d3 for every search, i3 / d4 only with MODE2).
 //
 // A workgroup walks `left` consecutive units of the line of (row tile, stage) pairs, starting at
 // (tile, st): the first full_tiles workgroups one whole row tile each, the others a run of the
@@ -417,8 +441,8 @@ template <int XT, int NW, int SK, bool GATED, bool MODE2>
 __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ aux, int stages_total, int full_tiles, int64_t tail_units,
-    int tail_quota, const float* __restrict__ thr, ic_top2_rec* __restrict__ part,
-    float* __restrict__ part3, float* __restrict__ rowband, uint32_t* __restrict__ zero_word) {
+    int tail_quota, const float* __restrict__ thr, PartBufs pb, float* __restrict__ rowband,
+    uint32_t* __restrict__ zero_word) {
   static_assert(XT == 1, "one 32-descriptor tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -532,8 +556,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
       best[0].d1 = start;
       best[0].d2 = start;
       best[0].d3 = start;
+      best[0].d4 = start;
       best[0].i1 = -1;
       best[0].i2 = -1;
+      best[0].i3 = -1;
       gate[0] = start;
     }
 
@@ -589,8 +615,12 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
         ic_top2_rec rec;
         rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
         const int64_t slot = part_slot(2 * piece + h, row, N, split_row0);
-        part[slot] = rec;
-        part3[slot] = b.d3;
+        pb.rec[slot] = rec;
+        pb.d3[slot] = b.d3;
+        if constexpr (MODE2) {
+          pb.i3[slot] = decode(b.i3);
+          pb.d4[slot] = b.d4;
+        }
         // the constant part of the row's band, for k_rescore's shortcut (same for every list)
         if (rowband && piece == 0 && h == 0) rowband[row] = c0[0];
       }
@@ -626,11 +656,12 @@ static bool gated_variant() {
 template <int NW, int SK>
 static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
                                   const float* aux, const AssignPlan& plan, bool mode2,
-                                  const float* thr, ic_top2_rec* part, float* part3,
-                                  float* rowband, uint32_t* zero_word, hipStream_t s) {
+                                  const float* thr, const PartBufs& pb, float* rowband,
+                                  uint32_t* zero_word, hipStream_t s) {
   const int64_t stages = (k + SK - 1) / SK;
   const int64_t tail_tiles = plan.row_tiles - plan.full_tiles;
-  auto kern = !gated_variant() ? k_top2_partial<kXT, NW, SK, false, false>
+  auto kern = !gated_variant() ? (mode2 ? k_top2_partial<kXT, NW, SK, false, true>
+                                        : k_top2_partial<kXT, NW, SK, false, false>)
               : mode2 ? k_top2_partial<kXT, NW, SK, true, true>
                       : k_top2_partial<kXT, NW, SK, true, false>;
   const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // allowed by assign_init() on this device
@@ -642,14 +673,15 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
                      (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota, thr,
-                     part, part3, rowband, zero_word);
+                     pb, rowband, zero_word);
   return hipGetLastError();
 }
 
 template <int NW, int SK>
 static hipError_t allow_lds() {
   const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // two stage buffers + a mean vector per wave
-  const void* kerns[3] = {reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, false, false>),
+  const void* kerns[4] = {reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, false, false>),
+                          reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, false, true>),
                           reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, true, false>),
                           reinterpret_cast<const void*>(k_top2_partial<kXT, NW, SK, true, true>)};
   for (const void* kp : kerns) {
@@ -675,14 +707,13 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n) {
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const AssignPlan& plan, bool mode2,
-                               const float* thr, ic_top2_rec* part, float* part3, float* rowband,
+                               const float* thr, const PartBufs& pb, float* rowband,
                                uint32_t* zero_word, hipStream_t s) {
+  if (!pb.rec || !pb.d3 || (mode2 && (!pb.i3 || !pb.d4))) return hipErrorInvalidValue;
   if (plan.waves == 8 && plan.stage_k == 64)
-    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband,
-                                  zero_word, s);
+    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, s);
   if (plan.waves == 16 && plan.stage_k == 128)
-    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, part, part3, rowband,
-                                    zero_word, s);
+    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, s);
   return hipErrorInvalidValue;
 }
 
@@ -783,8 +814,7 @@ __device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, floa
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
                                                  const float* __restrict__ aux,
-                                                 const ic_top2_rec* __restrict__ part,
-                                                 const float* __restrict__ part3,
+                                                 PartBufs pb,
                                                  const float* __restrict__ rowband, TailGeom tail,
                                                  int64_t split_row0, int mode2, int64_t chunk,
                                                  FinalOut out, int32_t* __restrict__ list,
@@ -809,23 +839,27 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
 
   // one row, by the 16 lanes of a group; a row that needs the direct search is put on the list
   auto full_look = [&](int64_t row) {
-    ic_top2_rec b = part[row];
-    float v3 = part3[row];
-    const int ns = n_lists(row);
-    // v3: third smallest value over all lists; u3: the smallest "third of one list", i.e. the
-    // best candidate whose INDEX no record holds
-    float u3 = v3;
-    for (int s = 1; s < ns; ++s) {
-      const int64_t slot = part_slot(s, row, N, split_row0);
-      const ic_top2_rec o = part[slot];
-      const float o3 = part3[slot];
-      u3 = __builtin_fminf(u3, o3);
-      v3 = third_of_union(b.d1, b.d2, v3, o.d1, o.d2, o3);
-      top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
-    }
+    // the row itself does not depend on the lists: its loads go out first and travel together
+    // with theirs
     const float* xrow = X + row * kD + sub * 8;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + 4);
+    ic_top2_rec b = pb.rec[row];
+    float v3 = pb.d3[row];
+    const int ns = n_lists(row);
+    // v3: third smallest value over all lists; u3: the smallest value a list holds without its
+    // index (the third of a list, the fourth when the search kept three indices), i.e. the best
+    // candidate whose INDEX no record holds
+    const float* __restrict__ unnamed = mode2 ? pb.d4 : pb.d3;
+    float u3 = unnamed[row];
+    for (int s = 1; s < ns; ++s) {
+      const int64_t slot = part_slot(s, row, N, split_row0);
+      const ic_top2_rec o = pb.rec[slot];
+      const float o3 = pb.d3[slot];
+      u3 = __builtin_fminf(u3, unnamed[slot]);
+      v3 = third_of_union(b.d1, b.d2, v3, o.d1, o.d2, o3);
+      top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
+    }
     const float xn = group16_sum(chain8(x0, x1, m0, m1));
     auto direct = [&](int idx) {
       const float* cr = C + (int64_t)idx * kD + sub * 8;
@@ -849,15 +883,16 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     }
     bool unsure = (v3 - ref) <= band;   // false on NaN / inf - inf
     if (unsure && !((u3 - ref) <= band)) {
-      // every candidate inside the band sits in the record of some list, index and all (no
-      // list has a third one there): evaluate them directly too and keep the two best of
-      // everything evaluated
+      // every candidate inside the band sits in some list with its index (no list holds an
+      // unnamed one there): evaluate them directly too and keep the two best of everything
+      // evaluated
       for (int s = 0; s < ns; ++s) {
-        const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
-        const int cand[2] = {o.i1, o.i2};
-        const float val[2] = {o.d1, o.d2};
+        const int64_t slot = part_slot(s, row, N, split_row0);
+        const ic_top2_rec o = pb.rec[slot];
+        const int cand[3] = {o.i1, o.i2, mode2 ? pb.i3[slot] : -1};
+        const float val[3] = {o.d1, o.d2, mode2 ? pb.d3[slot] : 0.f};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 3; ++t) {
           const int idx = cand[t];
           if (idx < 0 || idx == a1 || idx == a2 || !((val[t] - ref) <= band)) continue;
           const float sd = direct(idx);
@@ -884,10 +919,10 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       __syncthreads();
       const int64_t row = base + threadIdx.x;
       if (row < row_end) {
-        ic_top2_rec b = part[row];
+        ic_top2_rec b = pb.rec[row];
         const int ns = n_lists(row);
         for (int s = 1; s < ns; ++s) {
-          const ic_top2_rec o = part[part_slot(s, row, N, split_row0)];
+          const ic_top2_rec o = pb.rec[part_slot(s, row, N, split_row0)];
           top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
         }
         // the gate's band of the best: everything outside the pair lies above b.d2 or was
@@ -916,8 +951,7 @@ int64_t rescore_chunk(int64_t n) {
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const ic_top2_rec* part, const float* part3, const float* rowband,
-                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          const PartBufs& pb, const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s) {
   const int64_t chunk = rescore_chunk(n);
@@ -925,8 +959,8 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (grid < 1 || n >= 0x7fffffffLL) return hipErrorInvalidValue;
   // the shortcut answers with an index only
   if (rowband && (mode2 || d1 || !i1)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, part, part3,
-                     rowband, TailGeom{plan.stages, plan.tail_quota, plan.rows_per_wg},
+  if (mode2 && (!pb.i3 || !pb.d4)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, pb, rowband, TailGeom{plan.stages, plan.tail_quota, plan.rows_per_wg},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);
   return hipGetLastError();

@@ -49,13 +49,21 @@ size_t codebook_aux_scratch_bytes(int64_t k);
 hipError_t launch_codebook_aux(const float* c, int64_t k, float* aux, char* scratch,
                                hipStream_t s);
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
-// part [assign_part_records]: per K-split (|c-m|^2 - 2 (x-m).c, index) best and second best;
-// part3 the value of the third best.  mode2: the caller wants the second neighbour too.
+// The lists of a search, assign_part_records entries each: per row, piece of its row tile and
+// lane half the (|c-m|^2 - 2 (x-m).c, index) of the best and the second best, the value of the
+// third best and -- only when the caller wants the second neighbour too (mode2) -- the index of
+// the third best and the value of the fourth.
+struct PartBufs {
+  ic_top2_rec* rec;
+  float* d3;
+  int32_t* i3;   // mode2 only
+  float* d4;     // mode2 only
+};
 // rowband (may be NULL) [n]: the constant part of each row's band, for launch_rescore's shortcut.
 // zero_word (may be NULL): a device word the kernel clears (the flagged-row counter).
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const AssignPlan& plan, bool mode2,
-                               const float* thr, ic_top2_rec* part, float* part3, float* rowband,
+                               const float* thr, const PartBufs& pb, float* rowband,
                                uint32_t* zero_word, hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
@@ -69,8 +77,7 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
 // the best are answered from the records alone.
 int64_t rescore_chunk(int64_t n);
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const ic_top2_rec* part, const float* part3, const float* rowband,
-                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          const PartBufs& pb, const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s);
 // search the listed rows again by direct differences and overwrite their outputs.

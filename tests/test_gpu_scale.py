@@ -100,3 +100,71 @@ def test_config5_video_batch_share():
     assert np.array_equal(l1[[0, 999, 1999]].cpu().numpy(),
                           oracle.build_histogram([idx[i * per:(i + 1) * per].cpu().numpy()
                                                   for i in (0, 999, 1999)], k, "l1"))
+
+
+def test_config4_full_size_twenty_iterations_and_the_eight_way_sum():
+    """BASELINE config 4 whole on one GPU: 10M rows, 65 536 centroids, 20 Lloyd iterations.  Per
+    iteration: the inertia must not rise; the centroid sums of the eight 1.25M-row shards a node
+    would hold, added in rank order (what the all-reduce leaves, up to its own order), must equal
+    the unsharded sums to 1e-12 and give centroids within the 1e-4 the design asks for."""
+    n, k, shards = 10_000_000, 65_536, 8
+    x = sift_like_device(n, n_modes=4096, seed=7, device=DEV)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(8)
+    c = x[torch.randperm(n, device=DEV, generator=g)[:k]].clone()   # first K of a permutation
+    bounds = [n * r // shards for r in range(shards + 1)]
+    labels, prev = None, float("inf")
+    inertias = []
+    for it in range(20):
+        labels, dist = ops.assign_top1(x, c, hint=labels)
+        inertia = float((dist.double() ** 2).sum())
+        assert inertia <= prev * (1 + 1e-7), (it, inertia, prev)
+        prev = inertia
+        inertias.append(inertia)
+        sums, counts = ops.centroid_partials(x, labels, k)
+        acc_s = torch.zeros_like(sums)
+        acc_c = torch.zeros_like(counts)
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            s_r, c_r = ops.centroid_partials(x[lo:hi], labels[lo:hi], k)
+            acc_s += s_r
+            acc_c += c_r
+        assert torch.equal(acc_c, counts) and int(counts.sum()) == n
+        scale = sums.abs().max()
+        assert float((acc_s - sums).abs().max() / scale) <= 1e-12
+        new_c, _has = ops.centroid_finalize(sums, counts, c)
+        sharded_c, _ = ops.centroid_finalize(acc_s, acc_c, c)
+        err = ((sharded_c - new_c).abs() / new_c.abs().clamp_min(1e-3)).max()
+        assert float(err) <= 1e-4, (it, float(err))
+        c = new_c
+    print("config 4 inertia, iterations 1 / 2 / 5 / 20: %.6e %.6e %.6e %.6e"
+          % (inertias[0], inertias[1], inertias[4], inertias[19]))
+    assert inertias[19] < 0.9 * inertias[0]                 # the fit went somewhere
+    # the last labels against the direct float32 search on a sample of rows
+    c_prev_rows = torch.arange(0, n, n // 5000, device=DEV)[:5000]
+    e1 = ops.assign_top2_exact(x[c_prev_rows].contiguous(), c, 0.8)[0]
+    chk, _ = ops.assign_top1(x[c_prev_rows].contiguous(), c, want_dist=False)
+    assert torch.equal(chk, e1)
+
+
+def test_config5_full_size_equals_its_five_shards():
+    """BASELINE config 5 whole on one GPU: 10 000 frames x 2000 descriptors, 10k words, power-L2
+    histograms; the run over all 20M rows must equal, bit for bit, the five 4M-row shards."""
+    n_img, per, k, shards = 10_000, 2000, 10_000, 5
+    x = sift_like_device(n_img * per, n_modes=2048, seed=9, device=DEV)
+    cb = sift_like_device(k, n_modes=2048, seed=4, device=DEV)
+    aux = ops.codebook_aux(cb)
+    offsets = torch.from_numpy(image_offsets(n_img, per)).to(DEV)
+    idx, _ = ops.assign_top1(x, cb, aux, want_dist=False)
+    h = ops.hist(idx, offsets, k, "power_l2", 0.5)
+    assert torch.allclose((h * h).sum(1), torch.ones(n_img, dtype=torch.float64, device=DEV), rtol=1e-12)
+    fs = n_img // shards
+    sub_off = torch.from_numpy(image_offsets(fs, per)).to(DEV)
+    for s in range(shards):
+        lo, hi = s * fs * per, (s + 1) * fs * per
+        idx_s, _ = ops.assign_top1(x[lo:hi], cb, aux, want_dist=False)
+        assert torch.equal(idx_s, idx[lo:hi])
+        h_s = ops.hist(idx_s, sub_off, k, "power_l2", 0.5)
+        assert torch.equal(h_s, h[s * fs:(s + 1) * fs])
+        del h_s, idx_s
+    raw_total = int(ops.hist(idx, offsets, k, "none").sum())
+    assert raw_total == n_img * per
