@@ -41,6 +41,7 @@ _SIGNATURES = {
     "ic_profile_end": [_p, ctypes.POINTER(_c_d), ctypes.POINTER(_c_i64)],
     "ic_row_sqnorm": [_p, _p, _c_i64, _c_int, _p, _p],
     "ic_codebook_aux_floats": [_c_i64],
+    "ic_codebook_aux_floats_d": [_c_i64, _c_int],
     "ic_codebook_aux": [_p, _p, _c_i64, _c_int, _p, _p],
     "ic_debug_flagged": [_p, _p],
     "ic_assign_top1": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
@@ -60,7 +61,8 @@ _SIGNATURES = {
     "ic_ransac_homography": [_p, _p, _p, _c_i64, _c_int, _p, ctypes.c_uint64, _c_d, _c_int, _c_int,
                              _p, _p, _p, _p, _p, _p],
 }
-_RESTYPES = {"ic_last_error": ctypes.c_char_p, "ic_codebook_aux_floats": ctypes.c_int64}
+_RESTYPES = {"ic_last_error": ctypes.c_char_p, "ic_codebook_aux_floats": ctypes.c_int64,
+             "ic_codebook_aux_floats_d": ctypes.c_int64}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

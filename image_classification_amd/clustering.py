@@ -14,7 +14,7 @@ import numpy as np
 
 from .backend import default_backend
 
-MAX_DIM = 128   # widest row the descriptor search (and therefore the Lloyd loop) handles
+MAX_DIM = 2048   # widest row the descriptor search (and therefore the Lloyd loop) handles
 
 
 def kmeans_assign(x, codebook, backend=None, return_dist=False):
@@ -84,8 +84,8 @@ def kmeans_fit(x, k, iters=10, minit="points", missing="warn", rng=None, backend
     if x.size < 1:
         raise ValueError("Empty input is not supported.")
     if x.shape[1] > MAX_DIM:
-        raise ValueError("kmeans2: data has %d features, this device k-means handles at most %d "
-                         "(local image descriptors)" % (x.shape[1], MAX_DIM))
+        raise ValueError("kmeans2: data has %d features, this device k-means handles at most %d"
+                         % (x.shape[1], MAX_DIM))
     karr = np.asarray(k)
     if minit == "matrix" or karr.size > 1:
         init = np.array(karr, copy=True)

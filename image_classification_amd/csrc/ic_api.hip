@@ -170,13 +170,17 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   if (n < 0 || n >= 0x7fffffffLL || k < 1 || k > 0x7fffffffLL)
     return fail(IC_EINVAL, "%s: need 0 <= n < 2^31 and 1 <= k < 2^31 (n=%lld k=%lld)", who,
                 (long long)n, (long long)k);
-  if (d < 1 || d > ic::kD) return fail(IC_EINVAL, "%s: descriptor dimension %d not in [1,%d]", who, d, ic::kD);
+  if (d < 1 || d > ic::kMaxWideD)
+    return fail(IC_EINVAL, "%s: row width %d not in [1,%d]", who, d, ic::kMaxWideD);
   if (n == 0) return IC_OK;
   if (!x || !c) return fail(IC_EINVAL, "%s: x and c must not be NULL", who);
   if (!i1 && !rec) return fail(IC_EINVAL, "%s: no output buffer given", who);
+  // rows are searched in 128-column slabs: D columns after zero-padding
+  const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
+  const bool pad = d != D;
   // the kernels read rows, codewords and the auxiliary block 16 bytes at a time
-  if (d == ic::kD && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(c)) & 15))
-    return fail(IC_EINVAL, "%s: x and c must be 16-byte aligned when d = 128", who);
+  if (!pad && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(c)) & 15))
+    return fail(IC_EINVAL, "%s: x and c must be 16-byte aligned when d is a multiple of 128", who);
   if (reinterpret_cast<uintptr_t>(c_aux) & 15)
     return fail(IC_EINVAL, "%s: c_aux must be 16-byte aligned", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -188,13 +192,12 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
 
   const int64_t kpad = (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
   ic::AssignPlan plan;
-  ic::assign_plan(n, k, ctx->num_cus, &plan);
-  const bool pad = d != ic::kD;
+  ic::assign_plan(n, k, ctx->num_cus, &plan, D > ic::kD);
   const size_t records = (size_t)ic::assign_part_records(plan, n);
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
-  const size_t o_aux = c_aux ? 0 : take((size_t)(ic::kAuxNorms + kpad) * 4);
-  const size_t o_auxs = c_aux ? 0 : take(ic::codebook_aux_scratch_bytes(k));
+  const size_t o_aux = c_aux ? 0 : take((size_t)ic::aux_floats(kpad, D) * 4);
+  const size_t o_auxs = c_aux ? 0 : take(ic::codebook_aux_scratch_bytes(k, D));
   const size_t o_part = take(records * sizeof(ic_top2_rec));
   const size_t o_part3 = take(records * 4);
   const size_t o_part3i = mode2 ? take(records * 4) : 0;
@@ -203,13 +206,15 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   const size_t o_count = take(4);
   const size_t o_tickets = take((size_t)ic::kExactGrid * 4);
   const size_t o_expart = take((size_t)ic::kExactGrid * 16 * sizeof(ic_top2_rec));
-  const size_t o_xp = pad ? take((size_t)n * ic::kD * 4) : 0;
-  const size_t o_cp = pad ? take((size_t)k * ic::kD * 4) : 0;
+  const size_t o_xp = pad ? take((size_t)n * D * 4) : 0;
+  const size_t o_cp = pad ? take((size_t)k * D * 4) : 0;
   const size_t o_thr = hint ? take((size_t)n * 4) : 0;
   // index-only nearest-codeword calls: the search kernel leaves each row's band constant, and
   // k_rescore settles most rows from the records alone
   const bool index_only = !mode2 && !d1;
-  const size_t o_band = index_only ? take((size_t)n * 4) : 0;
+  const bool wide = D > ic::kD;
+  const size_t o_band = (index_only || wide) ? take((size_t)n * 4) : 0;
+  const size_t o_xc = wide ? take((size_t)n * D * 4) : 0;   // centred copy of wide rows
   int rc;
   char* ws;
   if (use_static) {
@@ -236,38 +241,42 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   if (pad) {
     float* xp = reinterpret_cast<float*>(ws + o_xp);
     float* cp = reinterpret_cast<float*>(ws + o_cp);
-    IC_HIP(ic::launch_pad_rows(x, n, d, xp, s), "pad descriptors");
-    IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
+    IC_HIP(ic::launch_pad_rows(x, n, d, D, xp, s), "pad descriptors");
+    IC_HIP(ic::launch_pad_rows(c, k, d, D, cp, s), "pad codebook");
     xs = xp;
     cs = cp;
   }
   const float* aux = c_aux;
   if (!aux) {
     float* a = reinterpret_cast<float*>(ws + o_aux);
-    IC_HIP(ic::launch_codebook_aux(cs, k, a, ws + o_auxs, s), "codebook auxiliary block");
+    IC_HIP(ic::launch_codebook_aux(cs, k, D, a, ws + o_auxs, s), "codebook auxiliary block");
     aux = a;
   }
+  const float* mean = aux + ic::aux_mean_offset(kpad, D);
   float* thr = nullptr;
   if (hint) {
     thr = reinterpret_cast<float*>(ws + o_thr);
-    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, aux, hint, thr, s), "hint threshold kernel");
+    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, aux, mean, D, hint, thr, s),
+           "hint threshold kernel");
   }
   hipEvent_t ev1 = nullptr;
   if (!use_static) {   // timing events are created on demand, which allocates
     rc = profile_open(ctx, s, &ev1);
     if (rc) return rc;
   }
-  float* rowband = index_only ? reinterpret_cast<float*>(ws + o_band) : nullptr;
+  float* rowband = (index_only || wide) ? reinterpret_cast<float*>(ws + o_band) : nullptr;
   int32_t* list = reinterpret_cast<int32_t*>(ws + o_list);
   uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
   uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + o_tickets);
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, plan, mode2, thr, pb, rowband, count, s),
+  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, mean, D, plan, mode2, thr, pb, rowband,
+                                 wide ? reinterpret_cast<float*>(ws + o_xc) : nullptr, count, s),
          "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
-  IC_HIP(ic::launch_rescore(xs, n, cs, aux, pb, rowband, plan, mode2, i1, d1, i2, d2,
+  if (!index_only) rowband = nullptr;   // k_rescore's shortcut answers index-only calls
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, mean, D, pb, rowband, plan, mode2, i1, d1, i2, d2,
                             ratio, mask, rec, list, count, tickets, s),
          "rescore kernel");
-  IC_HIP(ic::launch_exact_rows(xs, n, cs, k, list, count,
+  IC_HIP(ic::launch_exact_rows(xs, n, cs, k, D, list, count,
                                reinterpret_cast<ic_top2_rec*>(ws + o_expart), tickets, i1, d1, i2,
                                d2, ratio, mask, rec, s),
          "direct search of the flagged rows");
@@ -413,36 +422,41 @@ int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, vo
   return IC_OK;
 }
 
-int64_t ic_codebook_aux_floats(int64_t k) {
-  if (k < 1) return 0;
-  return ic::kAuxNorms + (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
+int64_t ic_codebook_aux_floats(int64_t k) { return ic_codebook_aux_floats_d(k, ic::kD); }
+
+int64_t ic_codebook_aux_floats_d(int64_t k, int d) {
+  if (k < 1 || d < 1 || d > ic::kMaxWideD) return 0;
+  const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
+  return ic::aux_floats((k + ic::kStageK - 1) / ic::kStageK * ic::kStageK, D);
 }
 
 int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, void* stream) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "ic_codebook_aux: invalid handle");
-  if (k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kD)
+  if (k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kMaxWideD)
     return fail(IC_EINVAL, "ic_codebook_aux: bad shape k=%lld d=%d", (long long)k, d);
   if (!c || !aux) return fail(IC_EINVAL, "ic_codebook_aux: NULL pointer");
-  if ((reinterpret_cast<uintptr_t>(aux) & 15) || (d == ic::kD && (reinterpret_cast<uintptr_t>(c) & 15)))
-    return fail(IC_EINVAL, "ic_codebook_aux: aux (and c when d = 128) must be 16-byte aligned");
+  const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
+  const bool pad = d != D;
+  if ((reinterpret_cast<uintptr_t>(aux) & 15) || (!pad && (reinterpret_cast<uintptr_t>(c) & 15)))
+    return fail(IC_EINVAL, "ic_codebook_aux: aux (and c when d is a multiple of 128) must be "
+                           "16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
-  const bool pad = d != ic::kD;
-  const size_t o_cp = align_up(ic::codebook_aux_scratch_bytes(k));
-  int rc = ensure_ws(ctx, o_cp + (pad ? align_up((size_t)k * ic::kD * 4) : 0));
+  const size_t o_cp = align_up(ic::codebook_aux_scratch_bytes(k, D));
+  int rc = ensure_ws(ctx, o_cp + (pad ? align_up((size_t)k * D * 4) : 0));
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
   const float* cs = c;
   if (pad) {
     float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
-    IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
+    IC_HIP(ic::launch_pad_rows(c, k, d, D, cp, s), "pad codebook");
     cs = cp;
   }
-  IC_HIP(ic::launch_codebook_aux(cs, k, aux, ctx->ws, s), "codebook auxiliary block");
+  IC_HIP(ic::launch_codebook_aux(cs, k, D, aux, ctx->ws, s), "codebook auxiliary block");
   return finish_call(ctx, s);
 }
 
@@ -490,34 +504,37 @@ int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c
                          uint8_t* mask, void* stream) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "ic_assign_top2_exact: invalid handle");
-  if (n < 0 || k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kD)
+  if (n < 0 || k < 1 || k > 0x7fffffffLL || d < 1 || d > ic::kMaxWideD)
     return fail(IC_EINVAL, "ic_assign_top2_exact: bad shape n=%lld k=%lld d=%d", (long long)n,
                 (long long)k, d);
   if (n == 0) return IC_OK;
   if (!x || !c || !i1) return fail(IC_EINVAL, "ic_assign_top2_exact: NULL pointer");
-  if (d == ic::kD && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(c)) & 15))
-    return fail(IC_EINVAL, "ic_assign_top2_exact: x and c must be 16-byte aligned when d = 128");
+  const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
+  if (d == D && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(c)) & 15))
+    return fail(IC_EINVAL, "ic_assign_top2_exact: x and c must be 16-byte aligned when d is a "
+                           "multiple of 128");
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
   const float* xs = x;
   const float* cs = c;
-  if (d != ic::kD) {
-    const size_t o_cp = align_up((size_t)n * ic::kD * 4);
-    int rc = ensure_ws(ctx, o_cp + align_up((size_t)k * ic::kD * 4));
+  if (d != D) {
+    const size_t o_cp = align_up((size_t)n * D * 4);
+    int rc = ensure_ws(ctx, o_cp + align_up((size_t)k * D * 4));
     if (rc) return rc;
     rc = order_after_previous(ctx, s);
     if (rc) return rc;
     float* xp = reinterpret_cast<float*>(ctx->ws);
     float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
-    IC_HIP(ic::launch_pad_rows(x, n, d, xp, s), "pad descriptors");
-    IC_HIP(ic::launch_pad_rows(c, k, d, cp, s), "pad codebook");
+    IC_HIP(ic::launch_pad_rows(x, n, d, D, xp, s), "pad descriptors");
+    IC_HIP(ic::launch_pad_rows(c, k, d, D, cp, s), "pad codebook");
     xs = xp;
     cs = cp;
   }
-  IC_HIP(ic::launch_exact_top2(xs, n, cs, k, i1, d1, i2, d2, ratio, mask, s), "direct search kernel");
-  return d != ic::kD ? finish_call(ctx, s) : IC_OK;
+  IC_HIP(ic::launch_exact_top2(xs, n, cs, k, D, i1, d1, i2, d2, ratio, mask, s),
+         "direct search kernel");
+  return d != D ? finish_call(ctx, s) : IC_OK;
 }
 
 int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
@@ -601,7 +618,7 @@ int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int
                          int d, double* sums, int64_t* counts, void* stream) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "ic_centroid_partials: invalid handle");
-  if (n < 0 || k < 1 || d < 1 || d > ic::kD)
+  if (n < 0 || k < 1 || d < 1 || d > ic::kMaxWideD)
     return fail(IC_EINVAL, "ic_centroid_partials: bad shape n=%lld k=%lld d=%d", (long long)n, (long long)k, d);
   if (!sums || !counts || (n > 0 && (!x || !codes)))
     return fail(IC_EINVAL, "ic_centroid_partials: NULL pointer");
@@ -616,6 +633,9 @@ int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int
   }
   ic::CentroidPlan plan;
   ic::centroid_plan(n, k, d, ctx->num_cus, &plan);
+  if (plan.use_scan && d > ic::kD)
+    return fail(IC_ELIMIT, "ic_centroid_partials: n=%lld x k=%lld is too large for rows wider than "
+                "%d columns", (long long)n, (long long)k, ic::kD);
   if (plan.use_scan) {
     int n_rr = 1;
     ic::centroid_plan_scan(n, k, ctx->num_cus, &n_rr);

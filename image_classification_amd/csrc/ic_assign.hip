@@ -93,13 +93,14 @@ constexpr int kSmallCodebook = 8192;   // below this: two 8-wave workgroups per 
 // the tail takes run g, which may end one row tile and begin the next.  Every workgroup then has
 // the same amount of matrix work, a row tile is loaded by at most max_pieces workgroups, and the
 // codebook stages keep streaming through LDS across the change of row tile.
-void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p) {
+void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide) {
   // IC_AMD_GEOMETRY forces a shape (1 = two 8-wave workgroups per CU, 2 = one of 16; tuning aid)
   static const int geom = [] {
     const char* v = getenv("IC_AMD_GEOMETRY");
     return v ? atoi(v) : 0;
   }();
-  const bool small = geom == 1 || (geom != 2 && k < kSmallCodebook);
+  // rows wider than 128 columns always take the 8-wave geometry (k_top2_wide has no other)
+  const bool small = wide || geom == 1 || (geom != 2 && k < kSmallCodebook);
   p->waves = small ? 8 : 16;
   p->stage_k = small ? 64 : 128;
   p->rows_per_wg = kXT * p->waves * 32;
@@ -199,6 +200,15 @@ constexpr float kGammaDirect = 129.f * kU;      // relative error bound of a 128
 __device__ __forceinline__ float error_bound(float xn_centred, float cn_max, float cr2_max) {
   return kU * (150.f * cn_max + 270.f * __builtin_sqrtf(xn_centred * cr2_max));
 }
+// Rows of D = 128 nslab columns (the wide search): the chain has D terms, the norm is a sum of
+// nslab partial sums.  D = 128 gives the constants above.
+__device__ __forceinline__ float error_bound_d(float xn_centred, float cn_max, float cr2_max,
+                                               int D) {
+  const float a = (float)(D + 21 + D / kD), b = (float)(2 * D + 14);
+  return kU * (a * cn_max + b * __builtin_sqrtf(xn_centred * cr2_max));
+}
+__device__ __forceinline__ float gamma_direct_d(int D) { return (float)(D + 1) * kU; }
+
 // Band below which another candidate may really be nearer than the reference candidate with
 // computed value v: two error bounds, plus the room the direct float32 evaluation of the two
 // squared distances (about R + v each, R = |x-m|^2 + 2 (x-m).m) needs to order them.
@@ -334,55 +344,60 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 // second best, which a plain top-2 search would have to rank, is skipped: about half the
 // ranking work of the top-2 gate.
 // Within a tile the gate of the tile's start is used (stale = larger = ranks a little more).
+template <bool MODE2>
+__device__ __forceinline__ void tile_epilogue_gated1(const f32x16& a, Top2& st, float& gate,
+                                                     float c0, int encbase, float one_plus_slope) {
+  const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
+                        min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
+                        __builtin_inff());
+  if (__builtin_amdgcn_ballot_w64(m < gate) != 0) {
+    // rank inside the tile with the register number (an inline constant) as index; -1 / -2 / -3
+    // stand for "the previous best / second / third best", resolved once after the 16 updates
+    float d1 = st.d1, d2 = st.d2, d3 = st.d3, d4 = st.d4;
+    const float g = gate;
+    int l1 = -1, l2 = -2, l3 = -3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
+        // lanes that did not pass: needless, never wrong
+        if constexpr (MODE2) top4_update(d1, d2, d3, d4, l1, l2, l3, a[r], r);
+        else top3_update(d1, d2, d3, l1, l2, a[r], r);
+      }
+    const int o1 = st.i1, o2 = st.i2;
+    st.d1 = d1;
+    st.d2 = d2;
+    st.d3 = d3;
+    st.i1 = l1 >= 0 ? encbase + l1 : o1;
+    st.i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
+    if constexpr (MODE2) {
+      st.d4 = d4;
+      st.i3 = l3 >= 0 ? encbase + l3 : (l3 == -1 ? o1 : (l3 == -2 ? o2 : st.i3));
+    }
+    gate = __builtin_fmaf(MODE2 ? d2 : d1, one_plus_slope, c0);
+  }
+}
+
 template <int XT, bool MODE2>
 __device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top2 (&st)[XT],
                                                     float (&gate)[XT], const float (&c0)[XT],
                                                     int encbase) {
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-    const f32x16& a = acc[xt];
-    const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
-                          min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
-                          __builtin_inff());
-    if (__builtin_amdgcn_ballot_w64(m < gate[xt]) != 0) {
-      // rank inside the tile with the register number (an inline constant) as index; -1 / -2
-      // stand for "the previous best / second best", resolved once after the 16 updates
-      float d1 = st[xt].d1, d2 = st[xt].d2, d3 = st[xt].d3, d4 = st[xt].d4;
-      const float g = gate[xt];
-      int l1 = -1, l2 = -2, l3 = -3;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
-          // lanes that did not pass: needless, never wrong
-          if constexpr (MODE2) top4_update(d1, d2, d3, d4, l1, l2, l3, a[r], r);
-          else top3_update(d1, d2, d3, l1, l2, a[r], r);
-        }
-      const int o1 = st[xt].i1, o2 = st[xt].i2;
-      st[xt].d1 = d1;
-      st[xt].d2 = d2;
-      st[xt].d3 = d3;
-      st[xt].i1 = l1 >= 0 ? encbase + l1 : o1;
-      st[xt].i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
-      if constexpr (MODE2) {
-        st[xt].d4 = d4;
-        st[xt].i3 = l3 >= 0 ? encbase + l3 : (l3 == -1 ? o1 : (l3 == -2 ? o2 : st[xt].i3));
-      }
-      gate[xt] = __builtin_fmaf(MODE2 ? d2 : d1, 1.f + kBandSlope, c0[xt]);
-    }
-  }
+  for (int xt = 0; xt < XT; ++xt)
+    tile_epilogue_gated1<MODE2>(acc[xt], st[xt], gate[xt], c0[xt], encbase, 1.f + kBandSlope);
 }
 
 // Every candidate ranked (IC_AMD_VARIANT=0: the timing baseline of the gate).
+__device__ __forceinline__ void tile_epilogue_all1(const f32x16& a, Top2& st, int encbase) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    top4_update(st.d1, st.d2, st.d3, st.d4, st.i1, st.i2, st.i3, a[r], encbase + r);
+}
+
 template <int XT>
 __device__ __forceinline__ void tile_epilogue_all(const f32x16 (&acc)[XT], Top2 (&st)[XT],
                                                   int encbase) {
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      top4_update(st[xt].d1, st[xt].d2, st[xt].d3, st[xt].d4, st[xt].i1, st[xt].i2, st[xt].i3,
-                  acc[xt][r], encbase + r);
-  }
+  for (int xt = 0; xt < XT; ++xt) tile_epilogue_all1(acc[xt], st[xt], encbase);
 }
 
 // Slot of row r's record in list l = 2 * (piece of its row tile) + (lane half).  The two lanes
@@ -677,6 +692,291 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The search for rows wider than 128 columns (D = 128 nslab, up to kMaxWideD): projected face
+// signatures and other long vectors (vision/facerec/face_indexing.py:141, :158 run vq / kmeans2
+// on them).  The geometry is the 8-wave one -- 32 rows per wave, stages of 64 codewords -- but a
+// stage now holds ONE 128-column slab of its 64 codewords, and the walk over a chunk of 64
+// codewords is a loop over the slabs: the wave loads that slab of its rows (they no longer fit in
+// registers for the whole sweep) from a copy that k_centre_rows has already centred on the mean
+// and scaled by -2 -- so the loaded registers are the MFMA operand as they are -- and the two
+// tiles' accumulators, started from |c - m|^2 at slab 0, carry the MFMA chain from slab to slab; after the last
+// slab they hold |c - m|^2 - 2 (x - m).c over all D columns and are ranked as in the 128-column
+// kernel.  Rounding bound and bands are those of a D-term chain (error_bound_d).  The row slabs
+// are re-read once per chunk of 64 codewords (32 FLOP per byte): this path is for correctness at
+// any width first; at D = 2048 and beyond a few hundred thousand rows it is bound by those reads.
+__device__ __forceinline__ void acc_from_norms(const char* cn_base, f32x16& acc, int h) {
+  const f32x4* cnv = reinterpret_cast<const f32x4*>(cn_base + h * 16);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 c4 = cnv[g * 2];
+    acc[g * 4 + 0] = c4[0];
+    acc[g * 4 + 1] = c4[1];
+    acc[g * 4 + 2] = c4[2];
+    acc[g * 4 + 3] = c4[3];
+  }
+}
+
+__device__ __forceinline__ void mfma_tile(const char* tile_base, const float (&xr)[64], f32x16& acc,
+                                          int i, int h) {
+  const f32x4* arow = reinterpret_cast<const f32x4*>(tile_base + i * kRowBytes + h * 16);
+  f32x4 a = arow[0];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    f32x4 an = a;
+    if (q + 1 < 16) an = arow[2 * (q + 1)];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], xr[q * 4 + e], acc, 0, 0, 0);
+    a = an;
+  }
+}
+
+// stage = slab `sl` (128 columns) of the 64 codewords of chunk `ch`; rows of C are D floats apart
+__device__ __forceinline__ void issue_stage_wide(const float* __restrict__ C, int K, int D,
+                                                 const float* __restrict__ cnp, int ch, int sl,
+                                                 char* sb, int wave, int lane) {
+  constexpr int NW = 8, SK = 64;
+  const char* base = reinterpret_cast<const char*>(C) + ((size_t)ch * SK * D + (size_t)sl * kD) * 4;
+  const int last = K - 1 - ch * SK;
+  const unsigned row_bytes = (unsigned)D * 4u;
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (int i = 0; i < (Stage<SK>::kGlds + NW - 1) / NW; ++i) {
+    const int m = wave + NW * i;
+    if (m < Stage<SK>::kGlds) {
+      const int pos = m * 64 + lane;
+      int r = (pos * 1986) >> 16;  // pos / 33, exact for pos < 4224
+      int c = pos - r * kRowChunks;
+      c = c == kRowChunks - 1 ? 0 : c;
+      r = r < last ? r : last;
+      const unsigned voff = (unsigned)r * row_bytes + (unsigned)c * 16u;
+      glds16(reinterpret_cast<const float*>(base + voff), sb + m * 1024);
+    }
+  }
+  if (wave == NW - 1) glds4(cnp + (size_t)ch * SK + lane, sb + Stage<SK>::kTileBytes);
+}
+
+__device__ __forceinline__ float group16_sum(float v);
+
+// out[row] = -2 (x[row] - m), c0[row] = the constant part of the row's band (see k_top2_partial):
+// 16 lanes per row, 128 columns after 128 columns.
+__global__ __launch_bounds__(256) void k_centre_rows(const float* __restrict__ X, int64_t N, int D,
+                                                     const float* __restrict__ aux,
+                                                     const float* __restrict__ mean,
+                                                     float* __restrict__ out,
+                                                     float* __restrict__ c0) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  const float band_slope = 4.f * gamma_direct_d(D);
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
+    float xn = 0.f, xm = 0.f;
+    for (int sl = 0; sl < D; sl += kD) {
+      const int64_t at = row * D + sl + sub * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float mu = mean[sl + sub * 8 + e];
+        const float t = X[at + e] - mu;
+        xn = __builtin_fmaf(t, t, xn);
+        xm = __builtin_fmaf(t, mu, xm);
+        out[at + e] = -2.0f * t;
+      }
+    }
+    xn = group16_sum(xn);
+    xm = group16_sum(xm);
+    if (sub == 0)
+      c0[row] = 2.01f * error_bound_d(xn, cn_max, cr2_max, D) + band_slope * (xn + 2.f * xm);
+  }
+}
+
+// XC: the rows centred and scaled by k_centre_rows; rowc0 [N]: their band constants.
+template <bool GATED, bool MODE2>
+__global__ __launch_bounds__(512, 4) void k_top2_wide(
+    const float* __restrict__ XC, int64_t N, const float* __restrict__ C, int K,
+    const float* __restrict__ aux, int D, int stages_total, int full_tiles, int64_t tail_units,
+    int tail_quota, const float* __restrict__ thr, PartBufs pb,
+    const float* __restrict__ rowc0, uint32_t* __restrict__ zero_word) {
+  constexpr int NW = 8, SK = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  const int nslab = D / kD;
+  const float* __restrict__ cnp = aux + kAuxNorms;
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
+
+  // the walk over (row tile, chunk of 64 codewords) units, as in k_top2_partial
+  int64_t tile = blockIdx.x;
+  int st = 0, left = stages_total, piece = 0;
+  if ((int)blockIdx.x >= full_tiles) {
+    const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
+    const int64_t tt = u / stages_total;
+    const int64_t rest = tail_units - u;
+    tile = full_tiles + tt;
+    st = (int)(u - tt * stages_total);
+    left = rest < tail_quota ? (int)rest : tail_quota;
+    piece = ((int)blockIdx.x - full_tiles) - (int)(tt * stages_total / tail_quota);
+  }
+  const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
+
+  // LDS stages follow each other as (chunk, slab 0 .. nslab-1), chunk after chunk
+  int ich = st, isl = 0;
+  int to_issue = left * nslab;
+  auto issue_next = [&](char* sb) {
+    issue_stage_wide(C, K, D, cnp, ich, isl, sb, wave, lane);
+    if (++isl == nslab) {
+      isl = 0;
+      ich = ich + 1 == stages_total ? 0 : ich + 1;
+    }
+    --to_issue;
+  };
+  issue_next(smem);
+  if (to_issue > 0) issue_next(smem + Stage<SK>::kBytes);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float band_slope = 4.f * gamma_direct_d(D);
+  int buf = 0;
+  for (;;) {
+    int64_t r = tile * (NW * 32) + wave * 32 + j;
+    const int64_t row = r;
+    r = r < N ? r : N - 1;
+    const float* xrow = XC + r * D + h * 4;
+    Top2 best[1];
+    float gate[1];
+    float c0[1] = {rowc0[r]};
+    {
+      float start = __builtin_inff();
+      if (thr) start = thr[r];
+      best[0].d1 = start;
+      best[0].d2 = start;
+      best[0].d3 = start;
+      best[0].d4 = start;
+      best[0].i1 = -1;
+      best[0].i2 = -1;
+      best[0].i3 = -1;
+      gate[0] = start;
+    }
+    const int item = stages_total - st < left ? stages_total - st : left;
+#pragma unroll 1
+    for (int i = 0; i < item; ++i, ++st) {
+      f32x16 acc0, acc1;
+#pragma unroll 1
+      for (int sl = 0; sl < nslab; ++sl) {
+        char* sb = smem + buf * Stage<SK>::kBytes;
+        // this slab of the wave's rows: already -2 (x - m), the MFMA operand as it is
+        float xr[64];
+        {
+          const f32x4* p = reinterpret_cast<const f32x4*>(xrow + sl * kD);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const f32x4 v = p[2 * q];
+            xr[q * 4 + 0] = v[0];
+            xr[q * 4 + 1] = v[1];
+            xr[q * 4 + 2] = v[2];
+            xr[q * 4 + 3] = v[3];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bool live = (st * 2 + t) * kTileK < K;
+          if (live) {
+            f32x16& acc = t == 0 ? acc0 : acc1;
+            if (sl == 0) acc_from_norms(sb + Stage<SK>::kTileBytes + t * kTileK * 4, acc, h);
+            mfma_tile(sb + t * kTileK * kRowBytes, xr, acc, j, h);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (to_issue > 0) issue_next(sb);
+        buf ^= 1;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if ((st * 2 + t) * kTileK < K) {
+          const int encbase = (st * 2 + t) * 16;
+          if constexpr (GATED)
+            tile_epilogue_gated1<MODE2>(t == 0 ? acc0 : acc1, best[0], gate[0], c0[0], encbase,
+                                        1.f + band_slope);
+          else
+            tile_epilogue_all1(t == 0 ? acc0 : acc1, best[0], encbase);
+        }
+      }
+    }
+    left -= item;
+    {
+      const Top2& b = best[0];
+      auto decode = [h](int enc) {
+        if (enc < 0) return -1;
+        const int t = enc >> 4, rr = enc & 15;
+        return t * kTileK + 8 * (rr >> 2) + 4 * h + (rr & 3);
+      };
+      if (row < N) {
+        ic_top2_rec rec;
+        rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
+        const int64_t slot = part_slot(2 * piece + h, row, N, split_row0);
+        pb.rec[slot] = rec;
+        pb.d3[slot] = b.d3;
+        if constexpr (MODE2) {
+          pb.i3[slot] = decode(b.i3);
+          pb.d4[slot] = b.d4;
+        }
+      }
+    }
+    if (left <= 0) break;
+    ++tile;
+    st = 0;
+    piece = 0;
+  }
+}
+
+// xc [n][D] and rowc0 [n] are workspace (launch_top2_partial's `wide_ws`): the centred copy of
+// the rows and their band constants.
+static hipError_t launch_wide(const float* x, int64_t n, const float* c, int64_t k,
+                              const float* aux, const float* mean, int D, const AssignPlan& plan,
+                              bool mode2, const float* thr, const PartBufs& pb, float* xc,
+                              float* rowc0, uint32_t* zero_word, hipStream_t s) {
+  const int64_t stages = (k + 63) / 64;
+  const int64_t tail_tiles = plan.row_tiles - plan.full_tiles;
+  if (plan.waves != 8 || plan.stage_k != 64 || stages != plan.stages || plan.tail_quota < 1 ||
+      plan.tail_wgs != (tail_tiles * stages + plan.tail_quota - 1) / plan.tail_quota ||
+      D <= kD || D % kD != 0 || D > kMaxWideD || !xc || !rowc0)
+    return hipErrorInvalidValue;
+  const int64_t grid = plan.full_tiles + plan.tail_wgs;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  int64_t cgrid = (n + 15) / 16;
+  if (cgrid > 16384) cgrid = 16384;
+  hipLaunchKernelGGL(k_centre_rows, dim3((unsigned)cgrid), dim3(256), 0, s, x, n, D, aux, mean, xc,
+                     rowc0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  auto kern = !gated_variant() ? (mode2 ? k_top2_wide<false, true> : k_top2_wide<false, false>)
+              : mode2 ? k_top2_wide<true, true>
+                      : k_top2_wide<true, false>;
+  const int lds = 2 * Stage<64>::kBytes;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, xc, n, c, (int)k, aux, D,
+                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota, thr,
+                     pb, rowc0, zero_word);
+  return hipGetLastError();
+}
+
+static hipError_t allow_lds_wide() {
+  const int lds = 2 * Stage<64>::kBytes;
+  const void* kerns[4] = {reinterpret_cast<const void*>(k_top2_wide<false, false>),
+                          reinterpret_cast<const void*>(k_top2_wide<false, true>),
+                          reinterpret_cast<const void*>(k_top2_wide<true, false>),
+                          reinterpret_cast<const void*>(k_top2_wide<true, true>)};
+  for (const void* kp : kerns) {
+    hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t exact_init();
+
 template <int NW, int SK>
 static hipError_t allow_lds() {
   const int lds = 2 * Stage<SK>::kBytes + NW * kD * 4;   // two stage buffers + a mean vector per wave
@@ -696,7 +996,11 @@ static hipError_t allow_lds() {
 hipError_t assign_init() {
   hipError_t e = allow_lds<8, 64>();
   if (e != hipSuccess) return e;
-  return allow_lds<16, 128>();
+  e = allow_lds<16, 128>();
+  if (e != hipSuccess) return e;
+  e = allow_lds_wide();
+  if (e != hipSuccess) return e;
+  return exact_init();
 }
 
 int64_t assign_part_records(const AssignPlan& p, int64_t n) {
@@ -706,10 +1010,14 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n) {
 }
 
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* aux, const AssignPlan& plan, bool mode2,
-                               const float* thr, const PartBufs& pb, float* rowband,
-                               uint32_t* zero_word, hipStream_t s) {
+                               const float* aux, const float* mean, int D, const AssignPlan& plan,
+                               bool mode2, const float* thr, const PartBufs& pb, float* rowband,
+                               float* wide_xc, uint32_t* zero_word, hipStream_t s) {
   if (!pb.rec || !pb.d3 || (mode2 && (!pb.i3 || !pb.d4))) return hipErrorInvalidValue;
+  if (D > kD)   // rowband is always filled for wide rows: it is where the kernel reads the bands
+    return launch_wide(x, n, c, k, aux, mean, D, plan, mode2, thr, pb, wide_xc, rowband,
+                       zero_word, s);
+  if (D != kD || mean != aux) return hipErrorInvalidValue;
   if (plan.waves == 8 && plan.stage_k == 64)
     return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, s);
   if (plan.waves == 16 && plan.stage_k == 128)
@@ -759,6 +1067,17 @@ __device__ __forceinline__ float group16_tree(float p) {
   const float b0 = __shfl(p, 0, 16), b1 = __shfl(p, 4, 16);
   const float b2 = __shfl(p, 8, 16), b3 = __shfl(p, 12, 16);
   return ((b0 + b1) + b2) + b3;
+}
+
+// The same for one 128-column slab of a wider row: the slab's four 32-component blocks are added
+// to `acc` one after the other, which is the order in which k_exact_top2 adds them.  With
+// acc = 0 the result equals group16_tree(p) bit for bit (0 + b0 is b0).
+__device__ __forceinline__ float group16_chain(float p, float acc) {
+  p += __shfl_xor(p, 1, 16);
+  p += __shfl_xor(p, 2, 16);
+  const float b0 = __shfl(p, 0, 16), b1 = __shfl(p, 4, 16);
+  const float b2 = __shfl(p, 8, 16), b3 = __shfl(p, 12, 16);
+  return (((acc + b0) + b1) + b2) + b3;
 }
 
 // 32 components of one (row, codeword) pair: xs points at the row's components in LDS, cv holds
@@ -811,9 +1130,15 @@ __device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, floa
 // every row whose second-best value lies outside the band of the best: no candidate can then be
 // nearer than the best by direct evaluation either, so its index is the answer and neither the
 // row nor any codeword is read again.  The other rows go through the pass below.
+//
+// WIDE: rows of D = 128 nslab columns (row stride D).  A row no longer fits a group's registers,
+// so every direct evaluation walks the row's slabs again (they stay in cache between the
+// candidates of a row), adding slab after slab in the order k_exact_top2 uses.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
-                                                 const float* __restrict__ aux,
+                                                 const float* __restrict__ aux, int D,
+                                                 const float* __restrict__ mean,
                                                  PartBufs pb,
                                                  const float* __restrict__ rowband, TailGeom tail,
                                                  int64_t split_row0, int mode2, int64_t chunk,
@@ -826,9 +1151,11 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   const int grp = threadIdx.x >> 4;
   const int64_t row_begin = (int64_t)blockIdx.x * chunk;
   const int64_t row_end = row_begin + chunk < N ? row_begin + chunk : N;
-  const f32x4 m0 = *reinterpret_cast<const f32x4*>(aux + sub * 8);
-  const f32x4 m1 = *reinterpret_cast<const f32x4*>(aux + sub * 8 + 4);
+  const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sub * 8);
+  const f32x4 m1 = *reinterpret_cast<const f32x4*>(mean + sub * 8 + 4);
   const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  const float band_slope = WIDE ? 4.f * gamma_direct_d(D) : kBandSlope;
+  const float flag_slope = WIDE ? 3.f * gamma_direct_d(D) : kFlagSlope;
   if (blockIdx.x == 0)
     for (int t = threadIdx.x; t < kExactGrid; t += 256) tickets[t] = 0;
   // lists of a row: the two lane halves of every piece of its row tile (rows below split_row0
@@ -841,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   auto full_look = [&](int64_t row) {
     // the row itself does not depend on the lists: its loads go out first and travel together
     // with theirs
-    const float* xrow = X + row * kD + sub * 8;
+    const float* xrow = X + row * (int64_t)(WIDE ? D : kD) + sub * 8;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + 4);
     ic_top2_rec b = pb.rec[row];
@@ -860,11 +1187,29 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       v3 = third_of_union(b.d1, b.d2, v3, o.d1, o.d2, o3);
       top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
     }
-    const float xn = group16_sum(chain8(x0, x1, m0, m1));
+    float xn = group16_sum(chain8(x0, x1, m0, m1));
+    if constexpr (WIDE) {
+      for (int sl = kD; sl < D; sl += kD)
+        xn += group16_sum(chain8(*reinterpret_cast<const f32x4*>(xrow + sl),
+                                 *reinterpret_cast<const f32x4*>(xrow + sl + 4),
+                                 *reinterpret_cast<const f32x4*>(mean + sl + sub * 8),
+                                 *reinterpret_cast<const f32x4*>(mean + sl + sub * 8 + 4)));
+    }
     auto direct = [&](int idx) {
-      const float* cr = C + (int64_t)idx * kD + sub * 8;
-      return group16_tree(chain8(x0, x1, *reinterpret_cast<const f32x4*>(cr),
-                                 *reinterpret_cast<const f32x4*>(cr + 4)));
+      const float* cr = C + (int64_t)idx * (WIDE ? D : kD) + sub * 8;
+      if constexpr (!WIDE) {
+        return group16_tree(chain8(x0, x1, *reinterpret_cast<const f32x4*>(cr),
+                                   *reinterpret_cast<const f32x4*>(cr + 4)));
+      } else {
+        float tot = group16_chain(chain8(x0, x1, *reinterpret_cast<const f32x4*>(cr),
+                                         *reinterpret_cast<const f32x4*>(cr + 4)), 0.f);
+        for (int sl = kD; sl < D; sl += kD)
+          tot = group16_chain(chain8(*reinterpret_cast<const f32x4*>(xrow + sl),
+                                     *reinterpret_cast<const f32x4*>(xrow + sl + 4),
+                                     *reinterpret_cast<const f32x4*>(cr + sl),
+                                     *reinterpret_cast<const f32x4*>(cr + sl + 4)), tot);
+        return tot;
+      }
     };
     float s1 = __builtin_inff(), s2 = __builtin_inff();
     if (b.i1 >= 0) s1 = direct(b.i1);
@@ -874,8 +1219,9 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     // plus what the direct evaluation needs to tell it from the reference candidate(s) -- whose
     // direct squared distance is s1 (the computed best) or, when both count, the larger of the two.
     const float ref = mode2 ? b.d2 : b.d1;
-    const float band = 2.f * error_bound(xn, cn_max, cr2_max) +
-                       kFlagSlope * (mode2 ? __builtin_fmaxf(s1, s2) : s1);
+    const float band = 2.f * (WIDE ? error_bound_d(xn, cn_max, cr2_max, D)
+                                   : error_bound(xn, cn_max, cr2_max)) +
+                       flag_slope * (mode2 ? __builtin_fmaxf(s1, s2) : s1);
     int a1 = b.i1, a2 = b.i2;
     if (a2 >= 0 && lex_less(s2, a2, s1, a1)) {
       const float ts = s1; s1 = s2; s2 = ts;
@@ -927,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
         }
         // the gate's band of the best: everything outside the pair lies above b.d2 or was
         // never ranked, and what was never ranked lies above this band as well
-        const float band = __builtin_fmaf(b.d1, kBandSlope, rowband[row]);
+        const float band = __builtin_fmaf(b.d1, band_slope, rowband[row]);
         if (b.i1 >= 0 && (b.d2 - b.d1) > band) {   // false on NaN
           out.i1[row] = b.i1;
         } else {
@@ -951,7 +1297,8 @@ int64_t rescore_chunk(int64_t n) {
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const PartBufs& pb, const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          const float* mean, int D, const PartBufs& pb, const float* rowband,
+                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s) {
   const int64_t chunk = rescore_chunk(n);
@@ -960,7 +1307,10 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   // the shortcut answers with an index only
   if (rowband && (mode2 || d1 || !i1)) return hipErrorInvalidValue;
   if (mode2 && (!pb.i3 || !pb.d4)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_rescore, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, pb, rowband, TailGeom{plan.stages, plan.tail_quota, plan.rows_per_wg},
+  if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
+  auto kern = D > kD ? k_rescore<true> : k_rescore<false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb,
+                     rowband, TailGeom{plan.stages, plan.tail_quota, plan.rows_per_wg},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);
   return hipGetLastError();
@@ -977,46 +1327,50 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
 __global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict__ X, int64_t N,
                                                         const float* __restrict__ C, int64_t K,
                                                         const float* __restrict__ aux,
+                                                        const float* __restrict__ mean, int D,
                                                         const int32_t* __restrict__ hint,
                                                         float* __restrict__ thr) {
   const int sub = threadIdx.x & 15;
   const int64_t stride = (int64_t)gridDim.x * 16;
-  const float* mu = aux + sub * 8;
   const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  const float band_slope = 4.f * gamma_direct_d(D);   // kBandSlope when D = 128
   for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < N; row += stride) {
     const int hraw = hint[row];
     const bool ok = hraw >= 0 && hraw < K;
     const int hh = ok ? hraw : 0;
-    const float* xrow = X + row * kD + sub * 8;
-    const float* crow = C + (int64_t)hh * kD + sub * 8;
+    const float* xrow = X + row * D + sub * 8;
+    const float* crow = C + (int64_t)hh * D + sub * 8;
     float dot = 0.f, xn = 0.f, xm = 0.f;
+    for (int sl = 0; sl < D; sl += kD) {
+      const float* mu = mean + sl + sub * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float t = xrow[e] - mu[e];
-      dot = __builtin_fmaf(t, crow[e], dot);
-      xn = __builtin_fmaf(t, t, xn);
-      xm = __builtin_fmaf(t, mu[e], xm);
+      for (int e = 0; e < 8; ++e) {
+        const float t = xrow[sl + e] - mu[e];
+        dot = __builtin_fmaf(t, crow[sl + e], dot);
+        xn = __builtin_fmaf(t, t, xn);
+        xm = __builtin_fmaf(t, mu[e], xm);
+      }
     }
     dot = group16_sum(dot);
     xn = group16_sum(xn);
     xm = group16_sum(xm);
     if (sub == 0) {
       const float v = aux[kAuxNorms + hh] - 2.f * dot;
-      const float bound = error_bound(xn, cn_max, cr2_max);
+      const float bound = error_bound_d(xn, cn_max, cr2_max, D);
       const float sq = __builtin_fmaxf(xn + 2.f * xm + v, 0.f);   // about the squared distance
-      thr[row] = ok ? v + 7.f * bound + kBandSlope * sq + 1e-30f : __builtin_inff();
+      thr[row] = ok ? v + 7.f * bound + band_slope * sq + 1e-30f : __builtin_inff();
     }
   }
 }
 
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
-                                 const float* aux, const int32_t* hint, float* thr,
-                                 hipStream_t s) {
+                                 const float* aux, const float* mean, int D, const int32_t* hint,
+                                 float* thr, hipStream_t s) {
   int64_t grid = (n + 15) / 16;
   if (grid > 16384) grid = 16384;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_hint_threshold, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, k, aux,
-                     hint, thr);
+                     mean, D, hint, thr);
   return hipGetLastError();
 }
 
@@ -1063,9 +1417,10 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
                                                     const uint32_t* __restrict__ count,
                                                     int max_pieces,
                                                     ic_top2_rec* __restrict__ partial,
-                                                    uint32_t* __restrict__ tickets,
+                                                    uint32_t* __restrict__ tickets, int D,
                                                     FinalOut fin) {
-  __shared__ __attribute__((aligned(16))) float xs[kExactRows][kD];
+  // the group's rows, [kExactRows][D] (D = 128 for descriptors, up to kMaxWideD)
+  extern __shared__ __attribute__((aligned(16))) float xs[];
   __shared__ uint32_t ticket;
   __shared__ float rd1[4][kExactRows], rd2[4][kExactRows];
   __shared__ int ri1[4][kExactRows], ri2[4][kExactRows];
@@ -1089,9 +1444,10 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
       rows[threadIdx.x] = list ? (int64_t)list[t] : t;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < kExactRows * kD / 4; e += 256) {
-      const int r = e / (kD / 4), q = e % (kD / 4);
-      reinterpret_cast<f32x4*>(&xs[r][0])[q] = reinterpret_cast<const f32x4*>(X + rows[r] * kD)[q];
+    const int D4 = D / 4;
+    for (int e = threadIdx.x; e < kExactRows * D4; e += 256) {
+      const int r = e / D4, q = e % D4;
+      reinterpret_cast<f32x4*>(xs + r * D)[q] = reinterpret_cast<const f32x4*>(X + rows[r] * D)[q];
     }
     __syncthreads();
     // rows of this group that exist (the last group of a short list is mostly padding, and a
@@ -1109,18 +1465,19 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
     auto scan = [&](auto full_tag) {
       constexpr bool kFull = decltype(full_tag)::value;
       for (int j = k0 + (int)threadIdx.x; j < k1; j += 256) {
-        const float* crow = C + (int64_t)j * kD;
+        const float* crow = C + (int64_t)j * D;
         float acc[kExactRows];
 #pragma unroll
         for (int r = 0; r < kExactRows; ++r) acc[r] = 0.f;
+        const int nblk = D / 32;
 #pragma unroll 1
-        for (int blk = 0; blk < 4; ++blk) {
+        for (int blk = 0; blk < nblk; ++blk) {
           f32x4 cv[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) cv[q] = *reinterpret_cast<const f32x4*>(crow + blk * 32 + q * 4);
 #pragma unroll
           for (int r = 0; r < kExactRows; ++r)
-            if (kFull || r < nr) acc[r] += block32(&xs[r][blk * 32], cv);
+            if (kFull || r < nr) acc[r] += block32(xs + r * D + blk * 32, cv);
         }
 #pragma unroll
         for (int r = 0; r < kExactRows; ++r)
@@ -1184,47 +1541,58 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
   }
 }
 
-hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t k, int32_t* i1,
-                             float* d1, int32_t* i2, float* d2, float ratio, uint8_t* mask,
-                             hipStream_t s) {
+// once per device: the direct search keeps 16 rows of up to kMaxWideD columns in dynamic LDS
+hipError_t exact_init() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_top2),
+                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                             kExactRows * kMaxWideD * 4);
+}
+
+hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t k, int D,
+                             int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                             uint8_t* mask, hipStream_t s) {
   const int64_t grid = (n + kExactRows - 1) / kExactRows;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_exact_top2, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, (int)k,
-                     (const int32_t*)nullptr, (const uint32_t*)nullptr, 1, (ic_top2_rec*)nullptr,
-                     (uint32_t*)nullptr, FinalOut{i1, d1, i2, d2, ratio, mask, nullptr});
+  if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_exact_top2, dim3((unsigned)grid), dim3(256), kExactRows * D * 4, s, x, n, c,
+                     (int)k, (const int32_t*)nullptr, (const uint32_t*)nullptr, 1,
+                     (ic_top2_rec*)nullptr, (uint32_t*)nullptr, D,
+                     FinalOut{i1, d1, i2, d2, ratio, mask, nullptr});
   return hipGetLastError();
 }
 
 // The second look at the flagged rows.  Their number is only known on the device, so the grid is
 // fixed (kExactGrid workgroups) and the kernel derives the decomposition from *count.  tickets
 // [kExactGrid] must be zero (k_rescore clears them).
-hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,
+hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k, int D,
                              const int32_t* list, const uint32_t* count, ic_top2_rec* partial,
                              uint32_t* tickets, int32_t* i1, float* d1, int32_t* i2, float* d2,
                              float ratio, uint8_t* mask, ic_top2_rec* rec, hipStream_t s) {
   const FinalOut fin{i1, d1, i2, d2, ratio, mask, rec};
-  hipLaunchKernelGGL(k_exact_top2, dim3(kExactGrid), dim3(256), 0, s, x, n, c, (int)k, list, count,
-                     kExactGrid, partial, tickets, fin);
+  if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_exact_top2, dim3(kExactGrid), dim3(256), kExactRows * D * 4, s, x, n, c,
+                     (int)k, list, count, kExactGrid, partial, tickets, D, fin);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
+// dst [n][D] <- src [n][d], zero beyond column d
 __global__ __launch_bounds__(256) void k_pad_rows(const float* __restrict__ src, int64_t n, int d,
-                                                  float* __restrict__ dst) {
-  const int64_t total = n * kD;
+                                                  int D, float* __restrict__ dst) {
+  const int64_t total = n * D;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * 256) {
-    const int64_t r = t / kD;
-    const int cidx = (int)(t % kD);
+    const int64_t r = t / D;
+    const int cidx = (int)(t % D);
     dst[t] = cidx < d ? src[r * d + cidx] : 0.f;
   }
 }
 
-hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s) {
-  int64_t grid = (n * kD + 255) / 256;
+hipError_t launch_pad_rows(const float* src, int64_t n, int d, int D, float* dst, hipStream_t s) {
+  int64_t grid = (n * D + 255) / 256;
   if (grid > 65536) grid = 65536;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)grid), dim3(256), 0, s, src, n, d, dst);
+  hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)grid), dim3(256), 0, s, src, n, d, D, dst);
   return hipGetLastError();
 }
 
@@ -1259,56 +1627,62 @@ hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipSt
 // of no concern; the sums run in a fixed order, so the block is reproducible.
 constexpr int kAuxSlabMax = 128;
 
-// slab g: column sums of rows [g rows_per_slab, ...) -> psum [slab][128]
-__global__ __launch_bounds__(256) void k_aux_colsum(const float* __restrict__ C, int64_t K,
+// slab g of rows, block y of 128 columns: column sums of rows [g rows_per_slab, ...) -> psum [slab][D]
+__global__ __launch_bounds__(256) void k_aux_colsum(const float* __restrict__ C, int64_t K, int D,
                                                     int64_t rows_per_slab,
                                                     float* __restrict__ psum) {
   __shared__ f32x4 red[8][32];
   const int col4 = threadIdx.x & 31, phase = threadIdx.x >> 5;
+  const int c0 = blockIdx.y * kD;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
   const int64_t r1 = r0 + rows_per_slab < K ? r0 + rows_per_slab : K;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int64_t r = r0 + phase; r < r1; r += 8)
-    acc += reinterpret_cast<const f32x4*>(C + r * kD)[col4];
+    acc += reinterpret_cast<const f32x4*>(C + r * D + c0)[col4];
   red[phase][col4] = acc;
   __syncthreads();
   if (phase == 0) {
     f32x4 t = red[0][col4];
     for (int p = 1; p < 8; ++p) t += red[p][col4];
-    reinterpret_cast<f32x4*>(psum + (int64_t)blockIdx.x * kD)[col4] = t;
+    reinterpret_cast<f32x4*>(psum + (int64_t)blockIdx.x * D + c0)[col4] = t;
   }
 }
 
 // Every workgroup folds the slab sums into the mean (same order everywhere, so the same bits),
-// then 16 lanes per codeword: centred and raw squared norm; per-workgroup maxima -> pmax.
-__global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, int64_t K,
+// then 16 lanes per codeword: centred and raw squared norm, 128 columns after 128 columns;
+// per-workgroup maxima -> pmax.  The mean goes to aux + mean_off.
+__global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, int64_t K, int D,
                                                    int64_t kpad, const float* __restrict__ psum,
                                                    int n_slabs, float* __restrict__ aux,
-                                                   float* __restrict__ pmax) {
-  __shared__ float mean[kD];
+                                                   int64_t mean_off, float* __restrict__ pmax) {
+  extern __shared__ __attribute__((aligned(16))) float mean[];   // [D]
   __shared__ float wmax[2][16];
-  if (threadIdx.x < kD) {
+  for (int col = threadIdx.x; col < D; col += 256) {
     double t = 0.0;
-    for (int g = 0; g < n_slabs; ++g) t += (double)psum[(int64_t)g * kD + threadIdx.x];
+    for (int g = 0; g < n_slabs; ++g) t += (double)psum[(int64_t)g * D + col];
     const float m = (float)(t / (double)K);
-    mean[threadIdx.x] = m;
-    if (blockIdx.x == 0) aux[threadIdx.x] = m;
+    mean[col] = m;
+    if (blockIdx.x == 0) aux[mean_off + col] = m;
   }
   __syncthreads();
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const f32x4 m0 = *reinterpret_cast<const f32x4*>(&mean[sub * 8]);
-  const f32x4 m1 = *reinterpret_cast<const f32x4*>(&mean[sub * 8 + 4]);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   float cmax = 0.f, rmax = 0.f;
   const int64_t stride = (int64_t)gridDim.x * 16;
   for (int64_t row = (int64_t)blockIdx.x * 16 + grp; row < kpad; row += stride) {
     float cn = __builtin_inff();
     if (row < K) {
-      const float* cr = C + row * kD + sub * 8;
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr);
-      const f32x4 c1 = *reinterpret_cast<const f32x4*>(cr + 4);
-      cn = group16_sum(chain8(c0, c1, m0, m1));
-      const float rn = group16_sum(chain8(c0, c1, zero, zero));
+      cn = 0.f;
+      float rn = 0.f;
+      for (int sl = 0; sl < D; sl += kD) {
+        const float* cr = C + row * D + sl + sub * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(&mean[sl + sub * 8]);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(&mean[sl + sub * 8 + 4]);
+        cn += group16_sum(chain8(c0, c1, m0, m1));
+        rn += group16_sum(chain8(c0, c1, zero, zero));
+      }
       cmax = __builtin_fmaxf(cmax, cn);
       rmax = __builtin_fmaxf(rmax, rn);
     }
@@ -1349,27 +1723,29 @@ static int aux_norm_grid(int64_t kpad) {
   return (int)(g > 512 ? 512 : (g < 1 ? 1 : g));
 }
 
-size_t codebook_aux_scratch_bytes(int64_t k) {
+size_t codebook_aux_scratch_bytes(int64_t k, int D) {
   const int64_t kpad = (k + kStageK - 1) / kStageK * kStageK;
-  return (size_t)kAuxSlabMax * kD * 4 + (size_t)aux_norm_grid(kpad) * 2 * 4;
+  return (size_t)kAuxSlabMax * D * 4 + (size_t)aux_norm_grid(kpad) * 2 * 4;
 }
 
-hipError_t launch_codebook_aux(const float* c, int64_t k, float* aux, char* scratch,
+// c [k][D] with D a multiple of 128 (narrower rows are padded by the caller)
+hipError_t launch_codebook_aux(const float* c, int64_t k, int D, float* aux, char* scratch,
                                hipStream_t s) {
+  if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
   const int64_t kpad = (k + kStageK - 1) / kStageK * kStageK;
   int64_t n_slabs = (k + 63) / 64;
   if (n_slabs > kAuxSlabMax) n_slabs = kAuxSlabMax;
   const int64_t rows_per_slab = (k + n_slabs - 1) / n_slabs;
   n_slabs = (k + rows_per_slab - 1) / rows_per_slab;
   float* psum = reinterpret_cast<float*>(scratch);
-  float* pmax = psum + (size_t)kAuxSlabMax * kD;
-  hipLaunchKernelGGL(k_aux_colsum, dim3((unsigned)n_slabs), dim3(256), 0, s, c, k, rows_per_slab,
-                     psum);
+  float* pmax = psum + (size_t)kAuxSlabMax * D;
+  hipLaunchKernelGGL(k_aux_colsum, dim3((unsigned)n_slabs, (unsigned)(D / kD)), dim3(256), 0, s, c,
+                     k, D, rows_per_slab, psum);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int grid = aux_norm_grid(kpad);
-  hipLaunchKernelGGL(k_aux_norms, dim3((unsigned)grid), dim3(256), 0, s, c, k, kpad, psum,
-                     (int)n_slabs, aux, pmax);
+  hipLaunchKernelGGL(k_aux_norms, dim3((unsigned)grid), dim3(256), D * 4, s, c, k, D, kpad, psum,
+                     (int)n_slabs, aux, aux_mean_offset(kpad, D), pmax);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_aux_max, dim3(1), dim3(64), 0, s, pmax, grid, aux);

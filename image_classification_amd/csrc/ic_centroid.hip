@@ -178,6 +178,10 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
   const int64_t b = blockIdx.x;
   const int64_t r = blockIdx.y;
   const int64_t c0 = b << kBucketShift;
+  // rows wider than 128 columns: workgroup z sums columns [128 z, 128 z + 128) (the partition is
+  // sorted again by each, which costs little next to the row gathers)
+  const int col0 = (int)blockIdx.z * kD;
+  const int dw = d - col0 < kD ? d - col0 : kD;   // columns of this slab
 
   for (int t = threadIdx.x; t < kBucketClusters * kD; t += kSumThreads) (&sums[0][0])[t] = 0.0;
   if (threadIdx.x < kBucketClusters) cnt[threadIdx.x] = 0;
@@ -214,8 +218,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
       // Every load below is unconditional (the tail re-reads the run's last row, lanes past the
       // row's end re-read component 0) and the unwanted values are dropped by selects afterwards:
       // a branch around a load makes the compiler wait for each load before issuing the next.
-      const int ca = c2 < d ? c2 : 0;
-      const int cb = c2 + 1 < d ? c2 + 1 : 0;
+      const int ca = col0 + (c2 < dw ? c2 : 0);
+      const int cb = col0 + (c2 + 1 < dw ? c2 + 1 : 0);
       for (int p = lo; p < hi; p += kRowsInFlight) {
         int rows[kRowsInFlight];
 #pragma unroll
@@ -239,8 +243,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {  // fixed order: ascending rows
           const bool live = p + u < hi;
-          a0 += (live && c2 < d) ? (double)v0[u] : 0.0;
-          a1 += (live && c2 + 1 < d) ? (double)v1[u] : 0.0;
+          a0 += (live && c2 < dw) ? (double)v0[u] : 0.0;
+          a1 += (live && c2 + 1 < dw) ? (double)v1[u] : 0.0;
         }
       }
       sums[lc][c2] += a0;
@@ -252,9 +256,10 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
 
   int64_t ncl = k - c0;
   if (ncl > kBucketClusters) ncl = kBucketClusters;
-  double* ps = psums + (r * k + c0) * d;
-  for (int t = threadIdx.x; t < (int)ncl * d; t += kSumThreads) ps[t] = sums[t / d][t % d];
-  if (threadIdx.x < ncl) pcounts[r * k + c0 + threadIdx.x] = cnt[threadIdx.x];
+  double* ps = psums + (r * k + c0) * d + col0;
+  for (int t = threadIdx.x; t < (int)ncl * dw; t += kSumThreads)
+    ps[(int64_t)(t / dw) * d + t % dw] = sums[t / dw][t % dw];
+  if (blockIdx.z == 0 && threadIdx.x < ncl) pcounts[r * k + c0 + threadIdx.x] = cnt[threadIdx.x];
 }
 
 void centroid_plan(int64_t n, int64_t k, int d, int num_cus, CentroidPlan* p) {
@@ -303,11 +308,12 @@ hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_
   hipLaunchKernelGGL(k_cent_bucketscan, dim3(1), dim3(1024), 0, s, total, p.nb, start);
   hipLaunchKernelGGL(k_cent_scatter, dim3((unsigned)p.nblk), dim3(256), 0, s, codes, n, p.nb, keys,
                      tab, start, perm);
+  const unsigned col_slabs = (unsigned)((d + kD - 1) / kD);
   if (d % 2 == 0)
-    hipLaunchKernelGGL(k_cent_sums<true>, dim3((unsigned)p.nb, (unsigned)p.n_ranges),
+    hipLaunchKernelGGL(k_cent_sums<true>, dim3((unsigned)p.nb, (unsigned)p.n_ranges, col_slabs),
                        dim3(kSumThreads), 0, s, x, d, k, perm, start, p.n_ranges, psums, pcounts);
   else
-    hipLaunchKernelGGL(k_cent_sums<false>, dim3((unsigned)p.nb, (unsigned)p.n_ranges),
+    hipLaunchKernelGGL(k_cent_sums<false>, dim3((unsigned)p.nb, (unsigned)p.n_ranges, col_slabs),
                        dim3(kSumThreads), 0, s, x, d, k, perm, start, p.n_ranges, psums, pcounts);
   e = hipGetLastError();
   if (e != hipSuccess || p.n_ranges == 1) return e;

@@ -28,25 +28,33 @@ struct AssignPlan {
   int tail_quota, max_pieces;
   int64_t tail_wgs;
 };
-void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p);
+// wide: rows of more than 128 columns (always the 8-wave geometry)
+void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide = false);
 // records the partial buffer of a plan holds: two per row (one per lane half), plus
 // 2 max_pieces - 2 more for every row of the tail
 int64_t assign_part_records(const AssignPlan& p, int64_t n);
 // once per device, with that device current: function attributes of the search kernels
 hipError_t assign_init();
 
-// The codebook's auxiliary block, float [kAuxNorms + kpad] (kpad = k rounded up to kStageK):
-constexpr int kAuxCnMax = 128;    // [0, 128) mean vector m; [128] max_j |c_j - m|^2
+// The codebook's auxiliary block, float [kAuxNorms + kpad] (kpad = k rounded up to kStageK) for
+// rows of up to 128 columns, [kAuxNorms + kpad + D] for wider rows (D = columns rounded up to a
+// multiple of 128), whose mean vector does not fit in front and lies behind the norms:
+constexpr int kAuxCnMax = 128;    // [0, 128) mean vector m (D = 128); [128] max_j |c_j - m|^2
 constexpr int kAuxCr2Max = 129;   // [129] max_j |c_j|^2
 constexpr int kAuxNorms = 256;    // [256 + j] = |c_j - m|^2 for j < k, +inf for k <= j < kpad
+constexpr int kMaxWideD = 2048;   // widest (padded) row the search handles
+inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? kAuxNorms + kpad : 0; }
+inline int64_t aux_floats(int64_t kpad, int D) { return kAuxNorms + kpad + (D > kD ? D : 0); }
 // the flagged rows' second look runs on a fixed grid; cut into pieces it holds at most one
 // partial record per (row, piece) with groups x pieces <= the grid, i.e. 16 * kExactGrid records
 constexpr int kExactGrid = 4096;
 
-hipError_t launch_pad_rows(const float* src, int64_t n, int d, float* dst, hipStream_t s);
-// aux <- auxiliary block of c [k][128]; scratch: codebook_aux_scratch_bytes(k) bytes
-size_t codebook_aux_scratch_bytes(int64_t k);
-hipError_t launch_codebook_aux(const float* c, int64_t k, float* aux, char* scratch,
+// dst [n][D] <- src [n][d] with zeros beyond column d
+hipError_t launch_pad_rows(const float* src, int64_t n, int d, int D, float* dst, hipStream_t s);
+// aux <- auxiliary block of c [k][D] (D a multiple of 128); scratch:
+// codebook_aux_scratch_bytes(k, D) bytes
+size_t codebook_aux_scratch_bytes(int64_t k, int D);
+hipError_t launch_codebook_aux(const float* c, int64_t k, int D, float* aux, char* scratch,
                                hipStream_t s);
 hipError_t launch_row_sqnorm(const float* x, int64_t n, int d, float* out, hipStream_t s);
 // The lists of a search, assign_part_records entries each: per row, piece of its row tile and
@@ -61,14 +69,17 @@ struct PartBufs {
 };
 // rowband (may be NULL) [n]: the constant part of each row's band, for launch_rescore's shortcut.
 // zero_word (may be NULL): a device word the kernel clears (the flagged-row counter).
+// x [n][D], c [k][D]; mean = the mean vector inside aux (aux itself when D = 128).  Rows wider
+// than 128 columns need rowband [n] (always) and wide_xc [n][D] floats of workspace, the centred
+// copy of the rows.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
-                               const float* aux, const AssignPlan& plan, bool mode2,
-                               const float* thr, const PartBufs& pb, float* rowband,
-                               uint32_t* zero_word, hipStream_t s);
+                               const float* aux, const float* mean, int D, const AssignPlan& plan,
+                               bool mode2, const float* thr, const PartBufs& pb, float* rowband,
+                               float* wide_xc, uint32_t* zero_word, hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
-                                 const float* aux, const int32_t* hint, float* thr,
-                                 hipStream_t s);
+                                 const float* aux, const float* mean, int D, const int32_t* hint,
+                                 float* thr, hipStream_t s);
 // merge the pieces, evaluate the two candidates as sum (x-c)^2, order, sqrt, ratio test; the
 // rows whose pair is not certain to hold the answer are appended to list [n] i32 (any order),
 // *count (cleared beforehand, see zero_word above) counts them; tickets [kExactGrid] u32 are
@@ -77,12 +88,12 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
 // the best are answered from the records alone.
 int64_t rescore_chunk(int64_t n);
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const PartBufs& pb, const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          const float* mean, int D, const PartBufs& pb, const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s);
 // search the listed rows again by direct differences and overwrite their outputs.
 // partial: 16 * kExactGrid records; tickets [kExactGrid], zero on entry.
-hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k,
+hipError_t launch_exact_rows(const float* x, int64_t n, const float* c, int64_t k, int D,
                              const int32_t* list, const uint32_t* count, ic_top2_rec* partial,
                              uint32_t* tickets, int32_t* i1, float* d1, int32_t* i2, float* d2,
                              float ratio, uint8_t* mask, ic_top2_rec* rec, hipStream_t s);
@@ -91,9 +102,9 @@ hipError_t launch_top2_merge(const ic_top2_rec* gathered, int n_shards, int64_t 
                              float* d2, float ratio, uint8_t* mask, hipStream_t s);
 
 // direct float32 search (sum (x-c)^2 per pair, no expansion): the on-device checker
-hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t k, int32_t* i1,
-                             float* d1, int32_t* i2, float* d2, float ratio, uint8_t* mask,
-                             hipStream_t s);
+hipError_t launch_exact_top2(const float* x, int64_t n, const float* c, int64_t k, int D,
+                             int32_t* i1, float* d1, int32_t* i2, float* d2, float ratio,
+                             uint8_t* mask, hipStream_t s);
 
 // ---- ic_reduce.hip ---------------------------------------------------------------------------
 hipError_t reduce_init();   // once per device: function attributes of the histogram kernel

@@ -14,13 +14,15 @@ import torch
 from . import _lib
 
 TOP2_REC_DTYPE = np.dtype([("d1", "<f4"), ("i1", "<i4"), ("d2", "<f4"), ("i2", "<i4")])
-MAX_DESCRIPTOR_DIM = 128   # the matrix-core search contracts over 128 columns (narrower rows are padded)
+# The matrix-core search contracts over slabs of 128 columns: rows of up to 128 columns (SURF-128 /
+# SIFT, narrower ones zero-padded) are the tuned case; wider rows, up to this limit, carry the
+# accumulators from slab to slab (the 1937-column face signatures of
+# vision/facerec/face_indexing.py:25 are quantised that way).
+MAX_DESCRIPTOR_DIM = 2048
 
 
 def check_descriptor_dim(d, who):
-    """The descriptor search handles local image descriptors of up to 128 columns (SURF-128 /
-    SIFT).  Wider rows -- e.g. the 1937-column face signatures of vision/facerec/face_indexing.py:25
-    -- are outside this path and are refused here, before anything is launched."""
+    """Rows wider than MAX_DESCRIPTOR_DIM are refused here, before anything is launched."""
     if int(d) > MAX_DESCRIPTOR_DIM:
         raise ValueError("%s: rows have %d columns, the descriptor search handles at most %d "
                          "(use ops.knn_rows / ops.pairwise for wider rows)"
@@ -86,8 +88,8 @@ def codebook_aux(c):
     check_descriptor_dim(c.shape[1], "codebook_aux")
     dev = _dev_index(c)
     lib = _lib.load()
-    aux = torch.empty(int(lib.ic_codebook_aux_floats(c.shape[0])), dtype=torch.float32,
-                      device=c.device)
+    aux = torch.empty(int(lib.ic_codebook_aux_floats_d(c.shape[0], c.shape[1])),
+                      dtype=torch.float32, device=c.device)
     rc = lib.ic_codebook_aux(_lib.handle(dev), _ptr(c), c.shape[0], c.shape[1], _ptr(aux),
                              _stream_ptr(dev))
     _lib.check(rc, "ic_codebook_aux")

@@ -22,9 +22,9 @@ def compute_vocab_features(vocab, feat, backend=None):
     if vocab.shape[1] != feat.shape[1]:
         raise ValueError("Incompatible dimension for X and Y matrices: X.shape[1] == %d while "
                          "Y.shape[1] == %d" % (feat.shape[1], vocab.shape[1]))
-    if feat.shape[1] > 128:
+    if feat.shape[1] > 2048:
         raise ValueError("compute_vocab_features: %d features per row, this device search handles "
-                         "at most 128 (local image descriptors)" % feat.shape[1])
+                         "at most 2048" % feat.shape[1])
     if feat.shape[0] == 0:
         return np.zeros(0, dtype=np.int64)
     b = backend or default_backend()

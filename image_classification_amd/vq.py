@@ -43,7 +43,7 @@ def vq(obs, code_book, check_finite=True, backend=None):
         raise ValueError("empty codebook (shape %s)" % (cb_a.shape,))
     if obs_a.shape[1] > MAX_DIM:
         raise ValueError("vq: observations have %d features, this device search handles at most "
-                         "%d (local image descriptors)" % (obs_a.shape[1], MAX_DIM))
+                         "%d" % (obs_a.shape[1], MAX_DIM))
     # scipy scans both arrays on the host first.  For a large observation matrix that scan costs
     # more than the whole device search, so it is replaced by a check of the result: with a finite
     # code book, a row holds an inf or NaN exactly when its distance is not finite.

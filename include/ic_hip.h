@@ -19,9 +19,13 @@
  *     not a device synchronisation), then frees and reallocates; ic_reserve_workspace does that
  *     up front.  Calls on one handle are serialised by a mutex, so a handle may be shared by
  *     threads.  Handles must not cross fork(): create one per process.
- *   - descriptor dimension d: 1 <= d <= 128 (rows are zero-padded to 128 internally).  With
- *     d = 128 the descriptor-search entry points (ic_assign_*, ic_codebook_aux) read x and c in
- *     place, 16 bytes at a time: both must be 16-byte aligned (IC_EINVAL otherwise).
+ *   - row width d of the descriptor-search entry points (ic_assign_*, ic_codebook_aux):
+ *     1 <= d <= 2048.  Rows are searched in slabs of 128 columns; a width that is not a multiple
+ *     of 128 is zero-padded into workspace copies first.  With d a multiple of 128 (the 128-d
+ *     local descriptors above all) x and c are read in place, 16 bytes at a time: both must be
+ *     16-byte aligned (IC_EINVAL otherwise).  d <= 128 is the tuned case; wider rows (the
+ *     projected face signatures of vision/facerec/face_indexing.py:141,158) run the same
+ *     algorithm with the row slabs re-read once per 64 codewords.
  */
 #ifndef IC_HIP_H
 #define IC_HIP_H
@@ -97,8 +101,11 @@ int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, vo
  * needs it; a caller that searches one codebook many times (a vocabulary, model/features.py:1166;
  * a logo database, model/robust_matching.py:73-80) computes it once and passes it as `c_aux`
  * instead of NULL.  It replaces the squared-norm terms scipy's _vq.vq and sklearn's
- * euclidean_distances recompute on every call.  aux [ic_codebook_aux_floats(k)] f32, device. */
+ * euclidean_distances recompute on every call.  aux [ic_codebook_aux_floats_d(k, d)] f32, device
+ * (ic_codebook_aux_floats(k) is the size for d <= 128: wider rows keep their mean vector, which
+ * no longer fits the block's fixed head, behind the norms). */
 int64_t ic_codebook_aux_floats(int64_t k);
+int64_t ic_codebook_aux_floats_d(int64_t k, int d);
 int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, void* stream);
 
 /* Test hook, no counterpart in the reference: after every following ic_assign_* call on this

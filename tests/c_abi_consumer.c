@@ -179,7 +179,7 @@ int main(void) {
     HIPCHECK(hipFree(de));
   }
   /* error convention */
-  if (ic_assign_top1(h, dx, N, dc, K, 200, NULL, di1, dd1, s) != IC_EINVAL) { ++bad; fprintf(stderr, "d=200 accepted\n"); }
+  if (ic_assign_top1(h, dx, N, dc, K, 4096, NULL, di1, dd1, s) != IC_EINVAL) { ++bad; fprintf(stderr, "d=4096 accepted\n"); }
   if (ic_hist(NULL, di1, doff, N_IMG, K, IC_NORM_L1, 0.5, dhist, s) != IC_EHANDLE) { ++bad; fprintf(stderr, "NULL handle accepted\n"); }
 
   ICCHECK(ic_destroy(h));

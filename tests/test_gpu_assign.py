@@ -408,6 +408,42 @@ def test_direct_search_vs_oracle(n, k, d):
         assert bad == 0
 
 
+@pytest.mark.parametrize("n,k,d", [(3000, 600, 400), (2500, 600, 1937), (700, 70, 129),
+                                   (40_000, 300, 256), (300, 5000, 640), (1000, 40, 2048)])
+def test_rows_wider_than_128_columns(n, k, d):
+    """Rows of more than 128 columns are searched in 128-column slabs with the accumulators
+    carried from slab to slab (the 1937-column face signatures of
+    vision/facerec/face_indexing.py:25 at :141 / :158; 600 clusters is face_index_builder.py:44's
+    default): the result must equal the direct float32 search bit for bit on every row, and the
+    float64 oracle under the gap rule."""
+    rng = np.random.default_rng(d)
+    centres = rng.standard_normal((64, d)).astype(np.float32) * 3
+    c = (centres[rng.integers(0, 64, k)] + rng.standard_normal((k, d))).astype(np.float32)
+    x = (centres[rng.integers(0, 64, n)] + rng.standard_normal((n, d))).astype(np.float32)
+    x[:20] = c[:20] + rng.normal(0, 1e-3, (20, d)).astype(np.float32)   # near-duplicates
+    f1, f2 = _same_as_direct(x, c)
+    assert f1 <= n // 10, (f1, n)      # the second look stays the exception at any width
+    ns = min(n, 1500)
+    rd, ri = oracle.topk(x[:ns], c, 3)
+    i1, d1, i2, d2, _ = _run_top2(x[:ns], c)
+    for got, rank in ((i1, 0), (i2, 1)):
+        must, bad, agree = oracle.check_indices(got, ri, rd, rank)
+        assert bad == 0 and agree >= 0.999
+    assert oracle.check_close(d1, rd[:, 0]) <= DIST_REL
+    # the hinted search (k-means iterations) gives the same answer
+    xd, cd = _dev(x), _dev(c)
+    plain, pd = ops.assign_top1(xd, cd)
+    hinted, hd = ops.assign_top1(xd, cd, hint=plain)
+    assert torch.equal(plain, hinted) and torch.equal(pd, hd)
+    # centroid sums of wide rows
+    sums, counts = ops.centroid_partials(xd, plain, k)
+    lab = plain.cpu().numpy()
+    ref = np.zeros((k, d))
+    np.add.at(ref, lab, x.astype(np.float64))
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(lab, minlength=k))
+    assert np.allclose(sums.cpu().numpy(), ref, rtol=1e-12, atol=1e-9)
+
+
 def test_one_dimensional_near_ties_are_strict_on_both_paths():
     # rows far closer to their neighbours than float32 resolves from the norms
     rng = np.random.default_rng(38)
@@ -430,8 +466,8 @@ def test_errors_are_loud():
     x = _dev(np.zeros((4, 128)))
     with pytest.raises(ValueError):
         ops.assign_top1(x, _dev(np.zeros((3, 64))))
-    with pytest.raises(ValueError, match="at most 128"):      # refused before any launch
-        ops.assign_top1(_dev(np.zeros((4, 200))), _dev(np.zeros((3, 200))))
+    with pytest.raises(ValueError, match="at most 2048"):     # refused before any launch
+        ops.assign_top1(_dev(np.zeros((4, 2100))), _dev(np.zeros((3, 2100))))
     with pytest.raises(ValueError):
         ops.assign_top1(x.cpu(), x)
 

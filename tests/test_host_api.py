@@ -548,18 +548,33 @@ def test_knn_scikit_rejects_what_sklearn_rejects(backend):
     assert np.array_equal(i, i_ref) and np.allclose(d, d_ref, atol=1e-6)
 
 
-def test_rows_wider_than_128_are_refused_with_a_value_error(backend):
-    # the 1937-column face signatures of vision/facerec/face_indexing.py:25 are outside this path
-    wide = np.zeros((6, 1937), dtype=np.float32)
-    with pytest.raises(ValueError, match="at most 128"):
-        vq(wide, wide[:2], backend=backend)
-    with pytest.raises(ValueError, match="at most 128"):
-        kmeans2(wide, 2, iter=1, backend=backend)
-    with pytest.raises(ValueError, match="at most 128"):
-        compute_vocab_features(wide[:2], wide, backend=backend)
+def test_face_signature_width_is_served_and_wider_rows_are_refused(backend):
+    # the 1937-column face signatures of vision/facerec/face_indexing.py:25 go through vq /
+    # kmeans2 / KMeansHashing (:141, :156-161) like any other row
+    rng = np.random.default_rng(5)
+    centres = rng.standard_normal((6, 1937)).astype(np.float32) * 4
+    feats = (centres[rng.integers(0, 6, 300)] + rng.standard_normal((300, 1937))).astype(np.float32)
+    code, dist = vq(feats, centres, backend=backend)
+    ref_code, ref_dist = oracle.vq(feats, centres)
+    assert np.array_equal(code, ref_code)
+    assert np.allclose(dist, ref_dist, rtol=1e-4)
+    cb, labels = kmeans2(feats, centres.copy(), iter=3, minit="matrix", backend=backend)
+    ref_cb, ref_labels, _ = oracle.kmeans2_matrix(feats, centres.copy(), 3)
+    assert np.array_equal(labels, ref_labels) and np.allclose(cb, ref_cb, rtol=1e-4, atol=1e-4)
     from image_classification_amd.face_indexing import KMeansHashing
-    with pytest.raises(ValueError, match="at most 128"):
-        KMeansHashing(wide[:2], [1, 1], backend=backend).get_hash(wide[0])
+    h = KMeansHashing(centres, [1] * 6, backend=backend)
+    assert h.get_hash(feats[0]) == str(ref_code[0])
+    assert h.get_hashes(feats[:50]) == [str(c) for c in ref_code[:50]]
+    codes = compute_vocab_features(centres, feats, backend=backend)
+    assert np.array_equal(codes, ref_code)
+    # beyond 2048 columns: a ValueError before anything is launched
+    wide = np.zeros((6, 2049), dtype=np.float32)
+    with pytest.raises(ValueError, match="at most 2048"):
+        vq(wide, wide[:2], backend=backend)
+    with pytest.raises(ValueError, match="at most 2048"):
+        kmeans2(wide, 2, iter=1, backend=backend)
+    with pytest.raises(ValueError, match="at most 2048"):
+        compute_vocab_features(wide[:2], wide, backend=backend)
 
 
 def test_codebook_fingerprint_sees_every_element():
