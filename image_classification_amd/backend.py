@@ -63,6 +63,20 @@ class HipBackend(object):
             return self.assign_top1(self.f32(x_np), cb, want_dist)
         return ops.assign_from_host_parts(parts, cb.c, cb.aux, top2=False, want_dist=want_dist)
 
+    def quantize_parts(self, parts, offsets, cb, k, norm="l1", power=0.5):
+        """(codes device tensor, histograms numpy float64 [n_img, k]) for descriptors held as a
+        list of host arrays: small inputs in three plain steps, large ones through the pipeline
+        that takes histogram blocks down while later rows are still being searched."""
+        total = sum(p.shape[0] for p in parts)
+        if total <= ops.HOST_CHUNK_ROWS * 2:
+            if parts:
+                codes, _ = self.assign_top1_parts(parts, cb, want_dist=False)
+            else:
+                codes = self.i32(np.empty(0, dtype=np.int32))
+            hists = self.hist(codes, self.i64(offsets), k, norm, power)
+            return codes, self.to_host(hists)
+        return ops.quantize_parts_to_host(parts, offsets, cb.c, cb.aux, k, norm, power)
+
     def assign_top2_parts(self, parts, cb, ratio=0.8):
         total = sum(p.shape[0] for p in parts)
         if total <= ops.HOST_CHUNK_ROWS // 4:

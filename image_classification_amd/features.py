@@ -157,12 +157,9 @@ class BagOfWords(object):
         return self.vocab
 
     # -- the hot path ----------------------------------------------------------------------------
-    def _assign_all(self, image_descs):
-        """One device call for every descriptor of every image.
-
-        Returns (codes int32 device tensor [total], offsets int64 numpy [n_img + 1]).
-        """
-        b = self._b()
+    @staticmethod
+    def _parts_and_offsets(image_descs):
+        """The non-empty descriptor arrays in image order and every image's row range."""
         rows = [0]
         parts = []
         for idesc in image_descs:
@@ -172,7 +169,15 @@ class BagOfWords(object):
                 if n:
                     parts.append(np.asarray(idesc.descriptors))
             rows.append(rows[-1] + n)
-        offsets = np.asarray(rows, dtype=np.int64)
+        return parts, np.asarray(rows, dtype=np.int64)
+
+    def _assign_all(self, image_descs):
+        """One device call for every descriptor of every image.
+
+        Returns (codes int32 device tensor [total], offsets int64 numpy [n_img + 1]).
+        """
+        b = self._b()
+        parts, offsets = self._parts_and_offsets(image_descs)
         if not parts:
             return b.i32(np.empty(0, dtype=np.int32)), offsets
         # no host-side concatenation: the per-image arrays are gathered into the upload buffer
@@ -180,11 +185,18 @@ class BagOfWords(object):
         return codes, offsets
 
     def _quantize(self, image_descs):
-        codes, offsets = self._assign_all(image_descs)
         if type(self)._build_histogram is BagOfWords._build_histogram:
             b = self._b()
+            if hasattr(b, "quantize_parts"):
+                # search, histograms and their way back to the host as one pipeline
+                parts, offsets = self._parts_and_offsets(image_descs)
+                _codes, hists = b.quantize_parts(parts, offsets, b.codebook(self.vocab),
+                                                 len(self.vocab), self.norm, self.power)
+                return image_descs, hists
+            codes, offsets = self._assign_all(image_descs)
             hists = b.hist(codes, b.i64(offsets), len(self.vocab), self.norm, self.power)
             return image_descs, b.to_host(hists)
+        codes, offsets = self._assign_all(image_descs)
         # a subclass builds its own histogram from per-image code lists (SpatialBagOfWords does,
         # model/features.py:1298-1308): hand it what the reference hands it
         host = codes.cpu().numpy()

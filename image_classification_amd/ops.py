@@ -249,7 +249,7 @@ def assign_from_host(x_np, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,
 _pinned = {}     # (pid, rows, d) -> [pinned tensor, pinned tensor]
 _staging_lock = threading.Lock()   # the staging buffers are shared by all threads of a process
 _gather_pool = None
-GATHER_THREADS = 4
+GATHER_THREADS = 8
 
 
 def _pinned_pair(rows, d):
@@ -282,7 +282,8 @@ def assign_from_host_parts(parts, c, c_aux=None, top2=False, ratio=0.8, want_dis
         return _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows)
 
 
-def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows):
+def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows,
+                            after_chunk=None):
     """Search rows held as a LIST of host arrays (one per image, any float dtype, [n_i, d]).
 
     The reference concatenates such lists on the host before every call; here worker threads
@@ -290,6 +291,8 @@ def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows)
     on the way), the staging buffer goes to the device on a second stream, and the search of a
     chunk runs while the next one is being gathered and uploaded.
     Returns what assign_top1 / assign_top2 return (device tensors covering all rows in order).
+    `after_chunk(outs, row_hi)`, when given, is called once the search of rows [0, row_hi) has
+    been enqueued on the current stream (what consumes the codes block by block hooks in here).
     """
     chunk_rows = int(chunk_rows or HOST_CHUNK_ROWS)
     d = c.shape[1]
@@ -311,20 +314,34 @@ def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows)
                 torch.empty(n, dtype=torch.float32, device=device) if want_dist else None)
     if n == 0:
         return outs
-    # copy jobs (part, lo, hi) grouped into chunks of at most chunk_rows rows
-    chunks, cur_jobs, cur_rows = [], [], 0
+    # Copy jobs (part, lo, hi) grouped into chunks.  The device idles while the first chunk is
+    # gathered and uploaded, and whatever follows the last chunk's search (histograms, the way
+    # back to the host) waits for all of it: so the chunks start small, double up to chunk_rows,
+    # and the last one is cut into halves again.
+    sizes, rem, cur_size = [], n, max(4096, chunk_rows // 16)
+    while rem > 0:
+        take = min(cur_size, rem)
+        sizes.append(take)
+        rem -= take
+        cur_size = min(chunk_rows, cur_size * 2)
+    last = sizes.pop()
+    while last > max(8192, chunk_rows // 8):
+        sizes.append(last - last // 2)
+        last //= 2
+    sizes.append(last)
+    chunks, cur_jobs, cur_rows, si = [], [], 0, 0
     for p in parts:
         lo = 0
         while lo < p.shape[0]:
-            take = min(p.shape[0] - lo, chunk_rows - cur_rows)
+            take = min(p.shape[0] - lo, sizes[si] - cur_rows)
             cur_jobs.append((p, lo, lo + take))
             cur_rows += take
             lo += take
-            if cur_rows == chunk_rows:
+            if cur_rows == sizes[si]:
                 chunks.append((cur_jobs, cur_rows))
                 cur_jobs, cur_rows = [], 0
-    if cur_rows:
-        chunks.append((cur_jobs, cur_rows))
+                si += 1
+    assert cur_rows == 0 and si == len(sizes)
     stage = _pinned_pair(chunk_rows, d)
     stage_np = [t.numpy() for t in stage]
     free = [None, None]            # event after which a staging buffer may be overwritten
@@ -361,10 +378,128 @@ def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows)
         else:
             assign_top1(xd, c, c_aux, want_dist, out=view)
         row0 += rows
+        if after_chunk is not None:
+            after_chunk(outs, row0)
     return outs
 
 
 TO_HOST_CHUNK_BYTES = 16 << 20
+
+
+def _touch_pages(buf):
+    buf[::4096] = 0
+
+
+def quantize_parts_to_host(parts, offsets_np, c, c_aux, k, norm="l1", power=0.5, chunk_rows=None):
+    """Codes and per-image histograms of images whose descriptors are a list of host arrays.
+
+    `parts` are the non-empty descriptor arrays in image order, `offsets_np` int64 [n_img + 1]
+    the row range of every image (empty images repeat an offset).  Returns (codes int32 device
+    tensor [total], histograms numpy float64 [n_img, k]).
+
+    One pipeline instead of three phases: while chunk i + 1 of the rows is gathered into
+    page-locked memory, uploaded and searched, the histograms of the images chunk i completed are
+    built (ic_hist into a row block of the device result) and that block travels back on a third
+    stream through its own page-locked buffers; worker threads move it into the final array,
+    whose pages other worker threads have touched while the first chunk was on its way (a fresh
+    76 MB array otherwise costs about 15 ms of page faults inside those copies).  The link
+    carries rows up and histograms down at the same time, and the download no longer follows the
+    search but hides behind it.
+    """
+    offsets_np = np.ascontiguousarray(offsets_np, dtype=np.int64)
+    n_img = offsets_np.shape[0] - 1
+    device = c.device
+    k = int(k)
+    out = np.empty((max(n_img, 0), k), dtype=np.float64)
+    if n_img <= 0:
+        return torch.empty(0, dtype=torch.int32, device=device), out
+    out_bytes = out.reshape(-1).view(np.uint8)
+    row_bytes = k * 8
+    with _staging_lock:
+        pool = _pool()
+        slab = -(-out_bytes.shape[0] // GATHER_THREADS)
+        touching = [pool.submit(_touch_pages, out_bytes[o:o + slab])
+                    for o in range(0, out_bytes.shape[0], max(slab, 1))]
+        offsets_dev = torch.from_numpy(offsets_np).to(device)
+        hist_dev = torch.empty((n_img, k), dtype=torch.float64, device=device)
+        hist_flat = hist_dev.view(-1).view(torch.uint8)
+        key = (os.getpid(), "hist_down")
+        stage = _pinned.get(key)
+        if stage is None:
+            stage = _pinned[key] = [torch.empty(TO_HOST_CHUNK_BYTES, dtype=torch.uint8).pin_memory()
+                                    for _ in range(2)]
+        stage_np = [s_.numpy() for s_ in stage]
+        down = _down_stream(device)
+        from concurrent.futures import ThreadPoolExecutor
+        courier = ThreadPoolExecutor(max_workers=1)   # takes the blocks down, one after the other
+        state = {"img_done": 0, "buf": 0, "pending": [None, None], "jobs": []}
+        rows_per_piece = max(1, TO_HOST_CHUNK_BYTES // row_bytes)
+
+        def take_down(ev_hist, img_lo, img_hi):
+            # courier thread: device block -> page-locked buffer -> (worker threads) final array
+            for f in touching:
+                f.result()
+            with torch.cuda.device(device):
+                for r0 in range(img_lo, img_hi, rows_per_piece):
+                    r1 = min(img_hi, r0 + rows_per_piece)
+                    lo, hi = r0 * row_bytes, r1 * row_bytes
+                    b = state["buf"]
+                    state["buf"] ^= 1
+                    if state["pending"][b] is not None:
+                        for f in state["pending"][b]:
+                            f.result()              # the copies out of this buffer are done
+                    with torch.cuda.stream(down):
+                        down.wait_event(ev_hist)
+                        stage[b][:hi - lo].copy_(hist_flat[lo:hi], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(down)
+                    ev.synchronize()
+                    step = max(1 << 20, -(-(hi - lo) // 4))
+                    state["pending"][b] = [
+                        pool.submit(np.copyto, out_bytes[lo + o:min(hi, lo + o + step)],
+                                    stage_np[b][o:min(hi - lo, o + step)])
+                        for o in range(0, hi - lo, step)]
+
+        def after_chunk(outs, row_hi):
+            # images whose last row has now been searched
+            img_hi = int(np.searchsorted(offsets_np, row_hi, side="right")) - 1
+            img_lo = state["img_done"]
+            if img_hi <= img_lo:
+                return
+            hist(outs[0], offsets_dev[img_lo:img_hi + 1], k, norm, power,
+                 out=hist_dev[img_lo:img_hi])
+            ev_hist = torch.cuda.Event()
+            ev_hist.record(torch.cuda.current_stream(device))
+            state["jobs"].append(courier.submit(take_down, ev_hist, img_lo, img_hi))
+            state["img_done"] = img_hi
+
+        try:
+            outs = _assign_from_host_parts(parts, c, c_aux, False, 0.8, False, chunk_rows,
+                                           after_chunk=after_chunk)
+            after_chunk(outs, int(offsets_np[-1]))          # trailing images without descriptors
+            if state["img_done"] < n_img:
+                raise ValueError("offsets do not cover the descriptors: %d rows, last offset %d"
+                                 % (outs[0].shape[0], int(offsets_np[-1])))
+            for j in state["jobs"]:
+                j.result()
+            for fs in state["pending"]:
+                for f in fs or ():
+                    f.result()
+        finally:
+            courier.shutdown(wait=True)
+        hist_dev.record_stream(down)
+    return outs[0], out
+
+
+_down_streams = {}
+
+
+def _down_stream(device):
+    key = (os.getpid(), str(device))
+    s = _down_streams.get(key)
+    if s is None:
+        s = _down_streams[key] = torch.cuda.Stream(device=device)
+    return s
 
 
 def to_host(t):
@@ -457,15 +592,22 @@ def top2_merge(gathered, shard_base, ratio=0.8, want_mask=True):
     return i1, d1, i2, d2, mask
 
 
-def hist(codes, offsets, k, norm="l1", power=0.5):
-    """codes int32 [total], offsets int64 [n_img+1] -> float64 [n_img, k] normalised histograms."""
+def hist(codes, offsets, k, norm="l1", power=0.5, out=None):
+    """codes int32 [total], offsets int64 [n_img+1] -> float64 [n_img, k] normalised histograms
+    (`out`: a preallocated contiguous float64 [n_img, k] device tensor, a row block of a larger one
+    for instance)."""
     if codes.dtype != torch.int32 or offsets.dtype != torch.int64:
         raise ValueError("codes must be int32 and offsets int64")
     if norm not in _lib.NORM_MODES:
         raise ValueError("norm must be one of %s" % sorted(_lib.NORM_MODES))
     dev = _dev_index(offsets)
     n_img = offsets.shape[0] - 1
-    out = torch.empty((n_img, int(k)), dtype=torch.float64, device=offsets.device)
+    if out is None:
+        out = torch.empty((n_img, int(k)), dtype=torch.float64, device=offsets.device)
+    elif (out.dtype != torch.float64 or tuple(out.shape) != (n_img, int(k))
+          or not out.is_contiguous() or out.device != offsets.device):
+        raise ValueError("out must be a contiguous float64 [%d, %d] tensor on %s"
+                         % (n_img, int(k), offsets.device))
     rc = _lib.load().ic_hist(_lib.handle(dev), _ptr(codes.contiguous()), _ptr(offsets.contiguous()),
                              n_img, int(k), _lib.NORM_MODES[norm], float(power), _ptr(out),
                              _stream_ptr(dev))

@@ -344,6 +344,40 @@ def test_gathered_parts_path_equals_device_path():
         ops.assign_from_host_parts([np.zeros((3, 64), np.float32)], cd, cn)
 
 
+@pytest.mark.parametrize("k,norm", [(300, "l1"), (70_000, "l2"), (1000, "power_l2")])
+def test_pipelined_quantise_equals_the_three_plain_steps(k, norm):
+    # search -> histogram -> download as one pipeline (blocks of histograms travel down while
+    # later rows are searched) must give the bytes of the three separate steps; small chunks force
+    # many blocks, images straddle chunk boundaries, some are empty, and 70 000 words make one
+    # image's histogram (560 KB) cut the 16 MB download pieces at odd places
+    rng = np.random.default_rng(k)
+    sizes = [int(v) for v in rng.integers(0, 900, size=60)]
+    sizes[0] = 0
+    sizes[17] = 0
+    sizes[-1] = 0
+    sizes[30] = 9000                       # one image spanning several chunks
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    x = sift_like(int(offsets[-1]), n_modes=128, seed=3)
+    c = sift_like(k, n_modes=128, seed=4)
+    parts = [x[offsets[i]:offsets[i + 1]].astype(np.float64 if i % 3 == 0 else np.float32)
+             for i in range(len(sizes)) if sizes[i]]
+    cd = _dev(c)
+    aux = ops.codebook_aux(cd)
+    codes, hists = ops.quantize_parts_to_host(parts, offsets, cd, aux, k, norm, 0.5, chunk_rows=4096)
+    ref_codes, _ = ops.assign_top1(_dev(x), cd, aux, want_dist=False)
+    ref_h = ops.hist(ref_codes, _dev_i64(offsets), k, norm, 0.5).cpu().numpy()
+    assert torch.equal(codes, ref_codes)
+    assert hists.dtype == np.float64 and hists.shape == (len(sizes), k)
+    assert np.array_equal(hists, ref_h)
+    # no descriptors at all: every histogram is an all-zero row
+    codes0, h0 = ops.quantize_parts_to_host([], np.zeros(4, np.int64), cd, aux, k, norm)
+    assert codes0.numel() == 0 and h0.shape == (3, k) and not h0.any()
+
+
+def _dev_i64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to("cuda")
+
+
 def test_staged_download_equals_plain_download():
     # results of tens of MB come back through page-locked staging buffers
     t = torch.arange(0, 9_000_000, dtype=torch.float64, device="cuda").reshape(3, -1) * 0.5

@@ -87,6 +87,21 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     print("BagOfWords.extract(%d images x 1000 descriptors, %d words): %.1f ms -> %.3g assignments/s"
           % (n_img, k, dt * 1e3, n_img * 1000 / dt), flush=True)
+# the same work as three plain phases (search of all rows, then all histograms, then the staged
+# download), alternating with the pipeline in one process
+b_ = bow._b()
+for rep in range(3):
+    t0 = time.perf_counter()
+    ids = bow._describe(list(range(n_img)))
+    codes_, offs_ = bow._assign_all(ids)
+    h3 = b_.to_host(b_.hist(codes_, b_.i64(offs_), len(bow.vocab), "l1", 0.5))
+    t_three = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, hp = bow.extract(list(range(n_img)))
+    t_pipe = time.perf_counter() - t0
+    assert np.array_equal(h3, hp)
+    print("  same process: three phases %.1f ms | pipeline %.1f ms" % (t_three * 1e3, t_pipe * 1e3),
+          flush=True)
 t0 = time.perf_counter()
 image_descs = bow._describe(list(range(n_img)))
 t1 = time.perf_counter()
