@@ -179,32 +179,47 @@ __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
       glds4(cnp + (size_t)st * SK + part * 64 + lane, sb + Stage<SK>::kTileBytes + part * 256);
 }
 
+// A lane's list.  The values are KEYS: the computed value with its four lowest mantissa bits
+// replaced by the number (0..15) of the accumulator register it came from, so that ranking a
+// candidate is three instructions on floats (insert into the ascending triple with min / med3)
+// and its place inside the tile needs no bookkeeping; the TILE a key came from is worked out once
+// per tile from which keys are new (resolve_tiles).  What the replaced bits cost in accuracy is
+// part of the rounding bound below.
 struct Top2 {
-  float d1, d2, d3;   // best, second best, and the VALUE of the third best
-  int i1, i2;
-  // searches that want the second neighbour too (MODE2) also keep the third best's index and
-  // the VALUE of the fourth: three candidates within the band of the second in one list are
+  float d1, d2, d3;   // keys of the best, the second best and the third best
+  int i1, i2;         // tiles of the best and the second best (-1: none)
+  // searches that want the second neighbour too (MODE2) also keep the third best's tile and
+  // the key of the fourth: three candidates within the band of the second in one list are
   // then still resolved by k_rescore instead of sending the row to the direct search
   float d4;
   int i3;
 };
+// "No candidate": what every list starts from.  The squared norms of the padding behind the last
+// codeword lie above it (kPadNorm), so padding is never ranked, and both are finite because a key
+// made from +inf would be a NaN.
+constexpr int kDenseTiles = 12;   // see tile_epilogue_gated1
+constexpr float kNone = 3.0e38f;
+constexpr float kPadNorm = 3.2e38f;
 
 // Rounding model.  The MFMA chain is a k-ordered float32 fma chain: starting from cn = |c - m|^2
 // it adds the 128 products -2 (x - m)_i c_i, one rounding each, every partial sum bounded by
 // cn + 2 |x - m| |c|.  With u = 2^-24, and 16 u cn for the rounding of cn itself and 2 u |x-m||c|
 // for that of x - m, the computed value differs from the exact one by at most
-//     u (144 cn + 258 |x - m| |c|)  <=  B := u (150 Cn + 270 |x - m| Cr),
-// Cn = max_j |c_j - m|^2, Cr = max_j |c_j|.
+//     u (144 cn + 258 |x - m| |c|)  <=  u (150 Cn + 270 |x - m| Cr),
+// Cn = max_j |c_j - m|^2, Cr = max_j |c_j|.  Turning the value into a key (four mantissa bits
+// replaced) moves it by less than 16 units in the last place, 32 u |v| with
+// |v| <= Cn + 2 |x - m| Cr, so the keys the lists hold differ from the exact values by at most
+//     B := u (182 Cn + 334 |x - m| Cr).
 constexpr float kU = 5.9604645e-8f;            // 2^-24
 constexpr float kGammaDirect = 129.f * kU;      // relative error bound of a 128-term sum (x-c)^2
 __device__ __forceinline__ float error_bound(float xn_centred, float cn_max, float cr2_max) {
-  return kU * (150.f * cn_max + 270.f * __builtin_sqrtf(xn_centred * cr2_max));
+  return kU * (182.f * cn_max + 334.f * __builtin_sqrtf(xn_centred * cr2_max));
 }
 // Rows of D = 128 nslab columns (the wide search): the chain has D terms, the norm is a sum of
 // nslab partial sums.  D = 128 gives the constants above.
 __device__ __forceinline__ float error_bound_d(float xn_centred, float cn_max, float cr2_max,
                                                int D) {
-  const float a = (float)(D + 21 + D / kD), b = (float)(2 * D + 14);
+  const float a = (float)(D + 53 + D / kD), b = (float)(2 * D + 78);
   return kU * (a * cn_max + b * __builtin_sqrtf(xn_centred * cr2_max));
 }
 __device__ __forceinline__ float gamma_direct_d(int D) { return (float)(D + 1) * kU; }
@@ -233,21 +248,19 @@ __device__ __forceinline__ void top2_update(float& d1r, float& d2r, int& i1r, in
   d1r = lt1 ? v : d1;
 }
 
-// The same, also keeping the third smallest value seen (d1 <= d2 <= d3 on entry and on exit).
-__device__ __forceinline__ void top3_update(float& d1r, float& d2r, float& d3r, int& i1r, int& i2r,
-                                            float v, int enc) {
-  d3r = __builtin_amdgcn_fmed3f(v, d2r, d3r);
-  top2_update(d1r, d2r, i1r, i2r, v, enc);
+// value -> key: the four lowest mantissa bits become the register number r (one v_and_or_b32)
+__device__ __forceinline__ float key_of(float v, int r) {
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & 0xfffffff0u) | (unsigned)r);
 }
-
-// The same with the third best's index and the fourth smallest value (d1 <= d2 <= d3 <= d4).
-__device__ __forceinline__ void top4_update(float& d1r, float& d2r, float& d3r, float& d4r,
-                                            int& i1r, int& i2r, int& i3r, float v, int enc) {
-  d4r = __builtin_amdgcn_fmed3f(v, d3r, d4r);
-  const int t = v < d3r ? enc : i3r;
-  i3r = v < d2r ? i2r : t;          // a new best or second best pushes the old second to third
-  d3r = __builtin_amdgcn_fmed3f(v, d2r, d3r);
-  top2_update(d1r, d2r, i1r, i2r, v, enc);
+// insert x into the ascending triple / quadruple, dropping the largest
+__device__ __forceinline__ void insert3(float& k1, float& k2, float& k3, float x) {
+  k3 = __builtin_amdgcn_fmed3f(k2, k3, x);
+  k2 = __builtin_amdgcn_fmed3f(k1, k2, x);
+  k1 = __builtin_fminf(k1, x);
+}
+__device__ __forceinline__ void insert4(float& k1, float& k2, float& k3, float& k4, float x) {
+  k4 = __builtin_amdgcn_fmed3f(k3, k4, x);
+  insert3(k1, k2, k3, x);
 }
 
 // Third smallest of the union of two ascending triples.
@@ -344,60 +357,103 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 // second best, which a plain top-2 search would have to rank, is skipped: about half the
 // ranking work of the top-2 gate.
 // Within a tile the gate of the tile's start is used (stale = larger = ranks a little more).
+// After a tile's keys have been inserted: which tiles do the list's keys come from?  The old
+// entries keep their order among themselves, so walking the new list from the front, an entry
+// is the next unused old one exactly when it equals it (a new key with the very same bits -- the
+// same register of another tile, the same value to sixteen units in the last place -- may take
+// an old entry's tile and leave its own to the twin behind it: either way the list names two
+// different candidates of that value); every other entry is new and belongs to `tile`.
+template <bool MODE2>
+__device__ __forceinline__ void resolve_tiles(Top2& st, float k1, float k2, float k3, float k4,
+                                              int tile) {
+  const float o1 = st.d1, o2 = st.d2, o3 = st.d3;
+  const int p1 = st.i1, p2 = st.i2, p3 = st.i3;
+  const bool e1 = k1 == o1;
+  const float a2 = e1 ? o2 : o1;
+  const int q2 = e1 ? p2 : p1;
+  const bool e2 = k2 == a2;
+  st.i1 = e1 ? p1 : tile;
+  st.i2 = e2 ? q2 : tile;
+  if constexpr (MODE2) {
+    const float x3 = e2 ? o3 : o2, y3 = e2 ? o2 : o1;
+    const int xq = e2 ? p3 : p2, yq = e2 ? p2 : p1;
+    const float a3 = e1 ? x3 : y3;
+    const int q3 = e1 ? xq : yq;
+    st.i3 = k3 == a3 ? q3 : tile;
+    st.d4 = k4;
+  }
+  st.d1 = k1;
+  st.d2 = k2;
+  st.d3 = k3;
+}
+
+// dense: the tile is one of the first of its scan, where nearly every register holds a candidate
+// some lane must rank: all sixteen are inserted without asking (straight-line code: sixteen
+// compare-and-branch pairs cost more than the inserts they would skip).
 template <bool MODE2>
 __device__ __forceinline__ void tile_epilogue_gated1(const f32x16& a, Top2& st, float& gate,
-                                                     float c0, int encbase, float one_plus_slope) {
+                                                     float c0, int tile, float one_plus_slope,
+                                                     bool dense = false) {
   const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
                         min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
                         __builtin_inff());
   if (__builtin_amdgcn_ballot_w64(m < gate) != 0) {
-    // rank inside the tile with the register number (an inline constant) as index; -1 / -2 / -3
-    // stand for "the previous best / second / third best", resolved once after the 16 updates
-    float d1 = st.d1, d2 = st.d2, d3 = st.d3, d4 = st.d4;
+    float k1 = st.d1, k2 = st.d2, k3 = st.d3, k4 = st.d4;
     const float g = gate;
-    int l1 = -1, l2 = -2, l3 = -3;
+    if (dense) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
-        // lanes that did not pass: needless, never wrong
-        if constexpr (MODE2) top4_update(d1, d2, d3, d4, l1, l2, l3, a[r], r);
-        else top3_update(d1, d2, d3, l1, l2, a[r], r);
+      for (int r = 0; r < 16; ++r) {
+        const float x = key_of(a[r], r);
+        if constexpr (MODE2) insert4(k1, k2, k3, k4, x);
+        else insert3(k1, k2, k3, x);
       }
-    const int o1 = st.i1, o2 = st.i2;
-    st.d1 = d1;
-    st.d2 = d2;
-    st.d3 = d3;
-    st.i1 = l1 >= 0 ? encbase + l1 : o1;
-    st.i2 = l2 >= 0 ? encbase + l2 : (l2 == -1 ? o1 : o2);
-    if constexpr (MODE2) {
-      st.d4 = d4;
-      st.i3 = l3 >= 0 ? encbase + l3 : (l3 == -1 ? o1 : (l3 == -2 ? o2 : st.i3));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
+          // lanes that did not pass: needless, never wrong
+          const float x = key_of(a[r], r);
+          if constexpr (MODE2) insert4(k1, k2, k3, k4, x);
+          else insert3(k1, k2, k3, x);
+        }
     }
-    gate = __builtin_fmaf(MODE2 ? d2 : d1, one_plus_slope, c0);
+    resolve_tiles<MODE2>(st, k1, k2, k3, k4, tile);
+    gate = __builtin_fmaf(MODE2 ? k2 : k1, one_plus_slope, c0);
   }
 }
 
 template <int XT, bool MODE2>
 __device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top2 (&st)[XT],
                                                     float (&gate)[XT], const float (&c0)[XT],
-                                                    int encbase) {
+                                                    int tile, bool dense) {
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt)
-    tile_epilogue_gated1<MODE2>(acc[xt], st[xt], gate[xt], c0[xt], encbase, 1.f + kBandSlope);
+    tile_epilogue_gated1<MODE2>(acc[xt], st[xt], gate[xt], c0[xt], tile, 1.f + kBandSlope, dense);
 }
 
 // Every candidate ranked (IC_AMD_VARIANT=0: the timing baseline of the gate).
-__device__ __forceinline__ void tile_epilogue_all1(const f32x16& a, Top2& st, int encbase) {
+__device__ __forceinline__ void tile_epilogue_all1(const f32x16& a, Top2& st, int tile) {
+  float k1 = st.d1, k2 = st.d2, k3 = st.d3, k4 = st.d4;
 #pragma unroll
-  for (int r = 0; r < 16; ++r)
-    top4_update(st.d1, st.d2, st.d3, st.d4, st.i1, st.i2, st.i3, a[r], encbase + r);
+  for (int r = 0; r < 16; ++r) insert4(k1, k2, k3, k4, key_of(a[r], r));
+  resolve_tiles<true>(st, k1, k2, k3, k4, tile);
 }
 
 template <int XT>
 __device__ __forceinline__ void tile_epilogue_all(const f32x16 (&acc)[XT], Top2 (&st)[XT],
-                                                  int encbase) {
+                                                  int tile) {
 #pragma unroll
-  for (int xt = 0; xt < XT; ++xt) tile_epilogue_all1(acc[xt], st[xt], encbase);
+  for (int xt = 0; xt < XT; ++xt) tile_epilogue_all1(acc[xt], st[xt], tile);
+}
+
+// (tile, key) -> codeword index: register g * 4 + e of lane half h is codeword 8 g + 4 h + e of
+// the tile
+// (an index at or beyond K can only come from non-finite input, whose keys are NaNs: none)
+__device__ __forceinline__ int decode_candidate(int tile, float key, int h, int K) {
+  if (tile < 0) return -1;
+  const int r = (int)(__builtin_bit_cast(unsigned, key) & 15u);
+  const int idx = tile * kTileK + 8 * (r >> 2) + 4 * h + (r & 3);
+  return idx < K ? idx : -1;
 }
 
 // Slot of row r's record in list l = 2 * (piece of its row tile) + (lane half).  The two lanes
@@ -566,7 +622,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     {
       // with a caller-supplied bound only candidates below it are ranked at all (index -1 =
       // none); the bound then stands for every candidate that was never looked at
-      float start = __builtin_inff();
+      float start = kNone;
       if (thr) start = thr[row < N ? row : N - 1];
       best[0].d1 = start;
       best[0].d2 = start;
@@ -609,31 +665,29 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
           if (to_issue > 0) issue_next(sb);
         }
         if (live) {
-          const int encbase = (st * Stage<SK>::kTiles + t) * 16;
-          if constexpr (GATED) tile_epilogue_gated<1, MODE2>(acc, best, gate, c0, encbase);
-          else tile_epilogue_all<1>(acc, best, encbase);
+          const int tile_no = st * Stage<SK>::kTiles + t;
+          // the first kDenseTiles tiles of a scan are ranked without per-register tests
+          const bool dense = i * Stage<SK>::kTiles + t < kDenseTiles;
+          if constexpr (GATED) tile_epilogue_gated<1, MODE2>(acc, best, gate, c0, tile_no, dense);
+          else tile_epilogue_all<1>(acc, best, tile_no);
         }
       }
       buf ^= 1;
     }
     left -= item;
 
-    // decode (tile, register) -> codeword index and store this lane's list
+    // (tile, key) -> codeword index, and store this lane's list
     {
       const Top2& b = best[0];
-      auto decode = [h](int enc) {
-        if (enc < 0) return -1;
-        const int t = enc >> 4, r = enc & 15;
-        return t * kTileK + 8 * (r >> 2) + 4 * h + (r & 3);
-      };
       if (row < N) {
         ic_top2_rec rec;
-        rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
+        rec.d1 = b.d1; rec.i1 = decode_candidate(b.i1, b.d1, h, K);
+        rec.d2 = b.d2; rec.i2 = decode_candidate(b.i2, b.d2, h, K);
         const int64_t slot = part_slot(2 * piece + h, row, N, split_row0);
         pb.rec[slot] = rec;
         pb.d3[slot] = b.d3;
         if constexpr (MODE2) {
-          pb.i3[slot] = decode(b.i3);
+          pb.i3[slot] = decode_candidate(b.i3, b.d3, h, K);
           pb.d4[slot] = b.d4;
         }
         // the constant part of the row's band, for k_rescore's shortcut (same for every list)
@@ -848,7 +902,7 @@ __global__ __launch_bounds__(512, 4) void k_top2_wide(
     float gate[1];
     float c0[1] = {rowc0[r]};
     {
-      float start = __builtin_inff();
+      float start = kNone;
       if (thr) start = thr[r];
       best[0].d1 = start;
       best[0].d2 = start;
@@ -896,31 +950,26 @@ __global__ __launch_bounds__(512, 4) void k_top2_wide(
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if ((st * 2 + t) * kTileK < K) {
-          const int encbase = (st * 2 + t) * 16;
           if constexpr (GATED)
-            tile_epilogue_gated1<MODE2>(t == 0 ? acc0 : acc1, best[0], gate[0], c0[0], encbase,
+            tile_epilogue_gated1<MODE2>(t == 0 ? acc0 : acc1, best[0], gate[0], c0[0], st * 2 + t,
                                         1.f + band_slope);
           else
-            tile_epilogue_all1(t == 0 ? acc0 : acc1, best[0], encbase);
+            tile_epilogue_all1(t == 0 ? acc0 : acc1, best[0], st * 2 + t);
         }
       }
     }
     left -= item;
     {
       const Top2& b = best[0];
-      auto decode = [h](int enc) {
-        if (enc < 0) return -1;
-        const int t = enc >> 4, rr = enc & 15;
-        return t * kTileK + 8 * (rr >> 2) + 4 * h + (rr & 3);
-      };
       if (row < N) {
         ic_top2_rec rec;
-        rec.d1 = b.d1; rec.i1 = decode(b.i1); rec.d2 = b.d2; rec.i2 = decode(b.i2);
+        rec.d1 = b.d1; rec.i1 = decode_candidate(b.i1, b.d1, h, K);
+        rec.d2 = b.d2; rec.i2 = decode_candidate(b.i2, b.d2, h, K);
         const int64_t slot = part_slot(2 * piece + h, row, N, split_row0);
         pb.rec[slot] = rec;
         pb.d3[slot] = b.d3;
         if constexpr (MODE2) {
-          pb.i3[slot] = decode(b.i3);
+          pb.i3[slot] = decode_candidate(b.i3, b.d3, h, K);
           pb.d4[slot] = b.d4;
         }
       }
@@ -1358,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict_
       const float v = aux[kAuxNorms + hh] - 2.f * dot;
       const float bound = error_bound_d(xn, cn_max, cr2_max, D);
       const float sq = __builtin_fmaxf(xn + 2.f * xm + v, 0.f);   // about the squared distance
-      thr[row] = ok ? v + 7.f * bound + band_slope * sq + 1e-30f : __builtin_inff();
+      thr[row] = ok ? __builtin_fminf(v + 7.f * bound + band_slope * sq + 1e-30f, kNone) : kNone;
     }
   }
 }
@@ -1670,7 +1719,7 @@ __global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, 
   float cmax = 0.f, rmax = 0.f;
   const int64_t stride = (int64_t)gridDim.x * 16;
   for (int64_t row = (int64_t)blockIdx.x * 16 + grp; row < kpad; row += stride) {
-    float cn = __builtin_inff();
+    float cn = kPadNorm;   // padding behind the last codeword: above every list's start value
     if (row < K) {
       cn = 0.f;
       float rn = 0.f;
