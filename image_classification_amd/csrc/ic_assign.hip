@@ -532,18 +532,21 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
 
   // where this workgroup's walk begins, how many units it has, and which piece of its first row
   // tile that is (a row tile entered at stage 0 is always piece 0)
-  int64_t tile = blockIdx.x;
+  // (rows are counted in 32 bits: the entry points refuse n >= 2^31, and 64-bit row numbers
+  // would keep loop-invariant register pairs alive across the sweep)
+  int tile = blockIdx.x;
   int st = 0, left = stages_total, piece = 0;
   if ((int)blockIdx.x >= full_tiles) {
     const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
     const int64_t tt = u / stages_total;
     const int64_t rest = tail_units - u;
-    tile = full_tiles + tt;
+    tile = full_tiles + (int)tt;
     st = (int)(u - tt * stages_total);
     left = rest < tail_quota ? (int)rest : tail_quota;
     piece = ((int)blockIdx.x - full_tiles) - (int)(tt * stages_total / tail_quota);
   }
   const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
+  const int n_rows = (int)N;
   // The codebook mean travels through a slot of LDS private to the wave (512 bytes behind the
   // stage buffers): its load is the first one issued, so it has landed long before the rows, and
   // nothing issued after the stage loads has to be waited for before the first MFMA.
@@ -564,10 +567,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
   for (;;) {
     // descriptors of this wave, 64 components per lane
     f32x4 xv[16];
+    const int row = tile * (NW * 32) + wave * 32 + j;
     {
-      int64_t r = tile * (NW * 32) + wave * 32 + j;
-      r = r < N ? r : N - 1;
-      const f32x4* p = reinterpret_cast<const f32x4*>(X + r * kD + h * 4);
+      const int r = row < n_rows ? row : n_rows - 1;
+      const f32x4* p = reinterpret_cast<const f32x4*>(X + (int64_t)r * kD + h * 4);
 #pragma unroll
       for (int q = 0; q < 16; ++q) xv[q] = p[2 * q];
     }
@@ -610,20 +613,23 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
           xm = __builtin_fmaf(t, mu[e], xm);
           xr[0][q * 4 + e] = -2.0f * t;
         }
+        // one chunk after the other: scheduled freely, the sixteen chunks' differences, products
+        // and mean values are all alive at once and a few registers spill to scratch memory
+        // (40 MB of HBM traffic per launch at 1 M rows)
+        __builtin_amdgcn_sched_barrier(0);
       }
       xn += __shfl_xor(xn, 32);
       xm += __shfl_xor(xm, 32);
       const float bound = error_bound(xn, cn_max, cr2_max);
       c0[0] = 2.01f * bound + kBandSlope * (xn + 2.f * xm);
     }
-    const int64_t row = tile * (NW * 32) + wave * 32 + j;
     Top2 best[1];
     float gate[1];
     {
       // with a caller-supplied bound only candidates below it are ranked at all (index -1 =
       // none); the bound then stands for every candidate that was never looked at
       float start = kNone;
-      if (thr) start = thr[row < N ? row : N - 1];
+      if (thr) start = thr[row < n_rows ? row : n_rows - 1];
       best[0].d1 = start;
       best[0].d2 = start;
       best[0].d3 = start;
@@ -679,7 +685,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     // (tile, key) -> codeword index, and store this lane's list
     {
       const Top2& b = best[0];
-      if (row < N) {
+      if (row < n_rows) {
         ic_top2_rec rec;
         rec.d1 = b.d1; rec.i1 = decode_candidate(b.i1, b.d1, h, K);
         rec.d2 = b.d2; rec.i2 = decode_candidate(b.i2, b.d2, h, K);
@@ -862,13 +868,13 @@ __global__ __launch_bounds__(512, 4) void k_top2_wide(
   if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
 
   // the walk over (row tile, chunk of 64 codewords) units, as in k_top2_partial
-  int64_t tile = blockIdx.x;
+  int tile = blockIdx.x;
   int st = 0, left = stages_total, piece = 0;
   if ((int)blockIdx.x >= full_tiles) {
     const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
     const int64_t tt = u / stages_total;
     const int64_t rest = tail_units - u;
-    tile = full_tiles + tt;
+    tile = full_tiles + (int)tt;
     st = (int)(u - tt * stages_total);
     left = rest < tail_quota ? (int)rest : tail_quota;
     piece = ((int)blockIdx.x - full_tiles) - (int)(tt * stages_total / tail_quota);
@@ -894,10 +900,9 @@ __global__ __launch_bounds__(512, 4) void k_top2_wide(
   const float band_slope = 4.f * gamma_direct_d(D);
   int buf = 0;
   for (;;) {
-    int64_t r = tile * (NW * 32) + wave * 32 + j;
-    const int64_t row = r;
-    r = r < N ? r : N - 1;
-    const float* xrow = XC + r * D + h * 4;
+    const int row = tile * (NW * 32) + wave * 32 + j;
+    const int r = row < (int)N ? row : (int)N - 1;
+    const float* xrow = XC + (int64_t)r * D + h * 4;
     Top2 best[1];
     float gate[1];
     float c0[1] = {rowc0[r]};
