@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ic_compact_matches": [_p, _p, _p, _p, _c_i64, _p, _c_i64, _p, _p, _p, _p, _p, _p],
     "ic_ransac_homography": [_p, _p, _p, _c_i64, _c_int, _p, ctypes.c_uint64, _c_d, _c_int, _c_int,
                              _p, _p, _p, _p, _p, _p],
+    "ic_host_gather_f32": [_p, _p, _p, _p, _c_i64, _c_int],
 }
 _RESTYPES = {"ic_last_error": ctypes.c_char_p, "ic_codebook_aux_floats": ctypes.c_int64,
              "ic_codebook_aux_floats_d": ctypes.c_int64}

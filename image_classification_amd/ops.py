@@ -4,6 +4,7 @@ torch is used for device memory and streams only; all arithmetic happens in libi
 numpy-in / numpy-out mirrors of the reference's call sites (vq.py, features.py, classifiers.py,
 robust_matching.py, scene_functions.py) are thin layers over these functions.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -209,58 +210,33 @@ def _copy_stream(device):
 
 def assign_from_host(x_np, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,
                      chunk_rows=None):
-    """Search rows that live in HOST memory (numpy float32 [n, d], C-contiguous).
-
-    The rows are uploaded in chunks on a second stream while the previous chunk is being searched
-    on the current stream, so the PCIe transfer hides behind the kernel instead of preceding it.
+    """Search rows that live in HOST memory (numpy [n, d]): the one-array case of
+    assign_from_host_parts, through the same page-locked upload pipeline (an upload straight from
+    pageable memory runs at less than half the link's rate).
     Returns what assign_top1 / assign_top2 return (device tensors covering all rows).
     """
-    chunk_rows = int(chunk_rows or HOST_CHUNK_ROWS)
-    n = x_np.shape[0]
-    device = c.device
-    if top2:
-        outs = (torch.empty(n, dtype=torch.int32, device=device),
-                torch.empty(n, dtype=torch.float32, device=device),
-                torch.empty(n, dtype=torch.int32, device=device),
-                torch.empty(n, dtype=torch.float32, device=device),
-                torch.empty(n, dtype=torch.uint8, device=device))
-    else:
-        outs = (torch.empty(n, dtype=torch.int32, device=device),
-                torch.empty(n, dtype=torch.float32, device=device) if want_dist else None)
-    cur = torch.cuda.current_stream(device)
-    side = _copy_stream(device)
-    side.wait_stream(cur)
-    for lo in range(0, n, chunk_rows):
-        hi = min(n, lo + chunk_rows)
-        with torch.cuda.stream(side):
-            xd = _from_numpy(x_np[lo:hi]).to(device, non_blocking=True)
-            ready = torch.cuda.Event()
-            ready.record(side)
-        cur.wait_event(ready)
-        xd.record_stream(cur)
-        view = tuple(o[lo:hi] if o is not None else None for o in outs)
-        if top2:
-            assign_top2(xd, c, ratio, c_aux, out=view)
-        else:
-            assign_top1(xd, c, c_aux, want_dist, out=view)
-    return outs
+    return assign_from_host_parts([x_np], c, c_aux, top2, ratio, want_dist, chunk_rows)
 
 
-_pinned = {}     # (pid, rows, d) -> [pinned tensor, pinned tensor]
+_pinned = {}     # (pid, rows, d) -> page-locked upload buffers; (pid, "hist_down") -> download buffers
 _staging_lock = threading.Lock()   # the staging buffers are shared by all threads of a process
 _gather_pool = None
 GATHER_THREADS = 8
+UPLOAD_CHUNK_BYTES = 32 << 20    # rows travel to the device in pieces of this size
+SEGMENT_CHUNKS = 4                # uploads that share one device buffer, the most one search takes
 
 
-def _pinned_pair(rows, d):
+def _pinned_set(rows, d):
+    """Three page-locked upload buffers of [rows, d] floats: one being gathered into, one whose
+    gather is queued behind it, one on its way to the device."""
     key = (os.getpid(), rows, d)
-    pair = _pinned.get(key)
-    if pair is None:
+    bufs = _pinned.get(key)
+    if bufs is None:
         for k in [k for k in _pinned if k[0] == key[0] and len(k) == 3]:   # one upload size per process
             del _pinned[k]
-        pair = _pinned[key] = [torch.empty((rows, d), dtype=torch.float32).pin_memory()
-                               for _ in range(2)]
-    return pair
+        bufs = _pinned[key] = [torch.empty((rows, d), dtype=torch.float32).pin_memory()
+                               for _ in range(3)]
+    return bufs
 
 
 def _pool():
@@ -272,8 +248,36 @@ def _pool():
     return _gather_pool
 
 
-def _copy_rows(dst, src):
-    np.copyto(dst, src, casting="same_kind")
+_gatherer = None
+_F64 = np.dtype(np.float64)
+
+
+def _gather_thread():
+    """The one Python thread that runs the native gathers, so that the calling thread can go on
+    enqueueing uploads and searches meanwhile (the copying itself happens on GATHER_THREADS native
+    threads that never need the interpreter lock)."""
+    global _gatherer
+    if _gatherer is None or getattr(_gatherer, "_pid", None) != os.getpid():
+        from concurrent.futures import ThreadPoolExecutor
+        _gatherer = ThreadPoolExecutor(max_workers=1)
+        _gatherer._pid = os.getpid()
+    return _gatherer
+
+
+def _gather_rows(dst, jobs, d):
+    """dst (page-locked float32 tensor) <- the row ranges (array, lo, hi) of `jobs`, one after the
+    other; the arrays are C-contiguous float32 or float64."""
+    n = len(jobs)
+    src = np.empty(n, dtype=np.uintp)
+    elems = np.empty(n, dtype=np.int64)
+    kind = np.empty(n, dtype=np.int32)
+    for j, (p, lo, hi) in enumerate(jobs):
+        src[j] = p.__array_interface__["data"][0] + lo * p.strides[0]
+        elems[j] = (hi - lo) * d
+        kind[j] = p.dtype == _F64
+    rc = _lib.load().ic_host_gather_f32(dst.data_ptr(), src.ctypes.data, elems.ctypes.data,
+                                        kind.ctypes.data, n, GATHER_THREADS)
+    _lib.check(rc, "ic_host_gather_f32")
 
 
 def assign_from_host_parts(parts, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,
@@ -288,21 +292,30 @@ def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows,
 
     The reference concatenates such lists on the host before every call; here worker threads
     gather the pieces straight into one of two page-locked staging buffers (converting to float32
-    on the way), the staging buffer goes to the device on a second stream, and the search of a
-    chunk runs while the next one is being gathered and uploaded.
+    on the way) and the staging buffer goes to the device on a second stream, in upload chunks of
+    UPLOAD_CHUNK_BYTES (`chunk_rows` rows when given).  Searches are cut independently of the
+    uploads: rows that have arrived are searched at once while fewer than two searches are
+    outstanding on the device, otherwise they wait and the next search takes them together with
+    what has arrived since (up to SEGMENT_CHUNKS uploads, which share one device buffer).  The
+    device therefore starts on the first small chunk, never idles while rows are available, and
+    once it falls behind the host it is handed few, large searches instead of many small ones.
     Returns what assign_top1 / assign_top2 return (device tensors covering all rows in order).
     `after_chunk(outs, row_hi)`, when given, is called once the search of rows [0, row_hi) has
     been enqueued on the current stream (what consumes the codes block by block hooks in here).
     """
-    chunk_rows = int(chunk_rows or HOST_CHUNK_ROWS)
     d = c.shape[1]
     device = c.device
-    n = 0
-    for p in parts:
+    n, own = 0, False
+    for i, p in enumerate(parts):
         if p.ndim != 2 or p.shape[1] != d:
             raise ValueError("dimension mismatch: a part has shape %s, codebook %d columns"
                              % (p.shape, d))
         n += p.shape[0]
+        if not p.flags.c_contiguous or p.dtype.char not in "fd":
+            # the native gather reads packed float32 / float64 rows; anything else is converted
+            if not own:
+                parts, own = list(parts), True      # the caller's list stays as it is
+            parts[i] = np.ascontiguousarray(p, dtype=np.float32)
     if top2:
         outs = (torch.empty(n, dtype=torch.int32, device=device),
                 torch.empty(n, dtype=torch.float32, device=device),
@@ -314,72 +327,108 @@ def _assign_from_host_parts(parts, c, c_aux, top2, ratio, want_dist, chunk_rows,
                 torch.empty(n, dtype=torch.float32, device=device) if want_dist else None)
     if n == 0:
         return outs
-    # Copy jobs (part, lo, hi) grouped into chunks.  The device idles while the first chunk is
-    # gathered and uploaded, and whatever follows the last chunk's search (histograms, the way
-    # back to the host) waits for all of it: so the chunks start small, double up to chunk_rows,
-    # and the last one is cut into halves again.
-    sizes, rem, cur_size = [], n, max(4096, chunk_rows // 16)
-    while rem > 0:
-        take = min(cur_size, rem)
-        sizes.append(take)
-        rem -= take
-        cur_size = min(chunk_rows, cur_size * 2)
-    last = sizes.pop()
-    while last > max(8192, chunk_rows // 8):
-        sizes.append(last - last // 2)
-        last //= 2
-    sizes.append(last)
-    chunks, cur_jobs, cur_rows, si = [], [], 0, 0
-    for p in parts:
-        lo = 0
-        while lo < p.shape[0]:
-            take = min(p.shape[0] - lo, sizes[si] - cur_rows)
-            cur_jobs.append((p, lo, lo + take))
-            cur_rows += take
-            lo += take
-            if cur_rows == sizes[si]:
-                chunks.append((cur_jobs, cur_rows))
-                cur_jobs, cur_rows = [], 0
-                si += 1
-    assert cur_rows == 0 and si == len(sizes)
-    stage = _pinned_pair(chunk_rows, d)
+    up_rows = int(chunk_rows) if chunk_rows else max(1024, UPLOAD_CHUNK_BYTES // (4 * d))
+    seg_rows = up_rows * SEGMENT_CHUNKS
+
+    def upload_chunks():
+        # (copy jobs, rows) per upload; the first two are a quarter and a half of the full size,
+        # so that the device has rows to search as early as possible
+        want = [max(1, up_rows // 4), max(1, up_rows // 2)]
+        jobs, rows = [], 0
+        for p in parts:
+            lo = 0
+            while lo < p.shape[0]:
+                size = want[0] if want else up_rows
+                take = min(p.shape[0] - lo, size - rows)
+                jobs.append((p, lo, lo + take))
+                rows += take
+                lo += take
+                if rows == size:
+                    yield jobs, rows
+                    jobs, rows = [], 0
+                    if want:
+                        want.pop(0)
+        if rows:
+            yield jobs, rows
+
+    stage = _pinned_set(up_rows, d)
     stage_np = [t.numpy() for t in stage]
-    free = [None, None]            # event after which a staging buffer may be overwritten
-    pool = _pool()
+    free = [None] * len(stage)     # event after which a staging buffer may be overwritten
+    gatherer = _gather_thread()
     cur = torch.cuda.current_stream(device)
     side = _copy_stream(device)
     side.wait_stream(cur)
-    row0 = 0
-    for ci, (jobs, rows) in enumerate(chunks):
-        b = ci & 1
-        if free[b] is not None:
-            free[b].synchronize()
-        futures, dst = [], 0
-        for p, lo, hi in jobs:
-            # large pieces are cut so that every worker thread gets a share of the copy
-            step = max(4096, -(-(hi - lo) // GATHER_THREADS))
-            for sub in range(lo, hi, step):
-                top = min(hi, sub + step)
-                futures.append(pool.submit(_copy_rows, stage_np[b][dst:dst + top - sub], p[sub:top]))
-                dst += top - sub
-        for f in futures:
-            f.result()
-        with torch.cuda.stream(side):
-            xd = torch.empty((rows, d), dtype=torch.float32, device=device)
-            xd.copy_(stage[b][:rows], non_blocking=True)
-            ready = torch.cuda.Event()
-            ready.record(side)
-        free[b] = ready
+    outstanding = collections.deque()      # events of the searches enqueued and not yet seen done
+    seg = None                             # device buffer of the current segment
+    seg_row0 = seg_fill = 0                # its first global row, rows uploaded into it so far
+    searched = 0                           # global rows whose search has been enqueued
+    ready = None
+
+    def search(upto):
+        # rows [searched, upto) of the current segment
+        nonlocal searched
         cur.wait_event(ready)
-        xd.record_stream(cur)
-        view = tuple(o[row0:row0 + rows] if o is not None else None for o in outs)
+        xd = seg[searched - seg_row0:upto - seg_row0]
+        view = tuple(o[searched:upto] if o is not None else None for o in outs)
         if top2:
             assign_top2(xd, c, ratio, c_aux, out=view)
         else:
             assign_top1(xd, c, c_aux, want_dist, out=view)
-        row0 += rows
+        done = torch.cuda.Event()
+        done.record(cur)
+        outstanding.append(done)
+        searched = upto
         if after_chunk is not None:
-            after_chunk(outs, row0)
+            after_chunk(outs, searched)
+
+    gen = upload_chunks()
+    gathering = collections.deque()        # (future, rows, staging buffer) of gathers under way
+    issued = 0
+
+    def gather_next():
+        # hands the next upload chunk to the gather thread, which is thereby never without work
+        # while this thread enqueues the upload and the search of the chunk before
+        nonlocal issued
+        nxt = next(gen, None)
+        if nxt is None:
+            return
+        jobs, rows = nxt
+        b = issued % len(stage)
+        issued += 1
+        if free[b] is not None:
+            free[b].synchronize()
+        gathering.append((gatherer.submit(_gather_rows, stage[b], jobs, d), rows, b))
+
+    gather_next()
+    gather_next()
+    while gathering:
+        future, rows, b = gathering.popleft()
+        future.result()
+        gather_next()
+        with torch.cuda.stream(side):
+            if seg is None:
+                seg_row0, seg_fill = seg_row0 + seg_fill, 0
+                seg = torch.empty((min(seg_rows, n - seg_row0), d), dtype=torch.float32,
+                                  device=device)
+                seg.record_stream(cur)
+            seg[seg_fill:seg_fill + rows].copy_(stage[b][:rows], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        free[b] = ready
+        seg_fill += rows
+        while outstanding and outstanding[0].query():
+            outstanding.popleft()
+        arrived = seg_row0 + seg_fill
+        if arrived == n:
+            # the end: what consumes the last search's output waits for all of it, so the rows
+            # still unsearched go in halves
+            while arrived - searched > max(up_rows // 2, 8192):
+                search(searched + (arrived - searched + 1) // 2)
+            search(arrived)
+        elif seg_fill + up_rows > seg.shape[0] or len(outstanding) < 2:
+            search(arrived)
+        if seg_fill + up_rows > seg.shape[0]:
+            seg = None                     # the next upload opens a new segment
     return outs
 
 

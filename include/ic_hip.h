@@ -267,6 +267,15 @@ int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets
                          int min_inliers, int accept_mean_err, double* H, int32_t* n_inliers,
                          double* best_err, int32_t* best_iter, uint8_t* inlier_mask, void* stream);
 
+/* Host-side helper of the upload path; touches no GPU and needs no handle.  Replaces the
+ * np.concatenate of the per-image descriptor arrays that precedes every search in the reference
+ * (model/features.py:1164): the n_jobs source blocks are laid one after the other into dst
+ * (normally a page-locked upload buffer) by `threads` plain threads that share the output
+ * evenly.  src[j] points to elems[j] values, float32 when kind[j] == 0 (kind may be NULL: all
+ * float32) or float64 when kind[j] == 1 (converted to float32).  All pointers are HOST memory. */
+int ic_host_gather_f32(float* dst, const void* const* src, const int64_t* elems,
+                       const int32_t* kind, int64_t n_jobs, int threads);
+
 #ifdef __cplusplus
 }
 #endif
