@@ -125,9 +125,9 @@ class HipBackend(object):
         return ops.compact_matches(mask, i1, row_offsets, kp_query, kp_rows)
 
     def ransac_homography(self, pts, offsets, n_iter, th, samples=None, seed=0, min_inliers=10,
-                          accept_mean_err=True):
+                          accept_mean_err=True, cv_rules=False):
         return ops.ransac_homography(pts, offsets, n_iter, th, samples, seed, min_inliers,
-                                     accept_mean_err)
+                                     accept_mean_err, cv_rules)
 
     def make_codebook(self, c_dev):
         """Wrap a device tensor produced by centroid_finalize as a codebook."""

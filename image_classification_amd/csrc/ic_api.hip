@@ -777,13 +777,15 @@ int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
 
 int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets, int64_t n_cand,
                          int n_iter, const int32_t* samples, uint64_t seed, double th,
-                         int min_inliers, int accept_mean_err, double* H, int32_t* n_inliers,
+                         int min_inliers, int flags, double* H, int32_t* n_inliers,
                          double* best_err, int32_t* best_iter, uint8_t* inlier_mask, void* stream) {
   Ctx* ctx = as_ctx(handle);
   if (!ctx) return fail(IC_EHANDLE, "ic_ransac_homography: invalid handle");
   if (n_cand < 0 || n_cand > 0x7fffffffLL || n_iter < 0 || n_iter > 65535 * 16)
     return fail(IC_EINVAL, "ic_ransac_homography: bad size n_cand=%lld n_iter=%d",
                 (long long)n_cand, n_iter);
+  if (flags & ~(IC_RANSAC_MEAN_ERR | IC_RANSAC_CV_RULES))
+    return fail(IC_EINVAL, "ic_ransac_homography: unknown flags %d", flags);
   if (n_cand == 0) return IC_OK;
   if (!pts || !offsets || !H || !n_inliers || !best_err || !inlier_mask)
     return fail(IC_EINVAL, "ic_ransac_homography: NULL pointer");
@@ -796,7 +798,7 @@ int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
   IC_HIP(ic::launch_ransac(pts, offsets, n_cand, n_iter, samples, seed, th, min_inliers,
-                           accept_mean_err, reinterpret_cast<int32_t*>(ctx->ws), H, n_inliers,
+                           flags, reinterpret_cast<int32_t*>(ctx->ws), H, n_inliers,
                            best_err, best_iter, inlier_mask, s),
          "homography RANSAC kernels");
   return finish_call(ctx, s);

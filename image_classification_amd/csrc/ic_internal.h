@@ -162,7 +162,7 @@ hipError_t launch_compact_matches(const uint8_t* mask, const int32_t* i1, const 
                                   int32_t* match_q, int32_t* match_im, double* pts, hipStream_t s);
 hipError_t launch_ransac(const double* pts, const int64_t* off, int64_t n_cand, int n_iter,
                          const int32_t* samples, uint64_t seed, double th, int min_inliers,
-                         int accept_mean_err, int32_t* n_inl_ws, double* H, int32_t* n_inliers,
+                         int flags, int32_t* n_inl_ws, double* H, int32_t* n_inliers,
                          double* best_err, int32_t* best_it, uint8_t* mask, hipStream_t s);
 
 }  // namespace ic

@@ -153,6 +153,27 @@ __device__ __forceinline__ double reproj_error(const double* H, double x, double
   return sqrt(dx * dx + dy * dy + dz * dz);
 }
 
+// Squared distance between the projected source point and the destination point, H[8] = 1: the
+// error OpenCV's homography estimator thresholds at th^2 (the rule behind the reference's default
+// cv2.findHomography(..., cv2.RANSAC, th), model/robust_matching.py:214-216).
+__device__ __forceinline__ double cv_sq_error(const double* H, double x, double y, double u,
+                                              double v) {
+  const double ww = 1.0 / (H[6] * x + H[7] * y + 1.0);
+  const double dx = (H[0] * x + H[1] * y + H[2]) * ww - u;
+  const double dy = (H[3] * x + H[4] * y + H[5]) * ww - v;
+  return dx * dx + dy * dy;
+}
+
+// Iteration limit after a model with `good` of n inliers at confidence 0.995 and four-point
+// samples, never above `limit` (OpenCV's RANSACUpdateNumIters).
+__device__ __forceinline__ int cv_num_iters(int good, int n, int limit) {
+  const double w = (double)good / (double)n;
+  const double denom = 1.0 - w * w * w * w;
+  if (denom < 2.2250738585072014e-308) return 0;
+  const double x = log(1.0 - 0.995) / log(denom);
+  return x >= (double)limit ? limit : (int)rint(x);
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
@@ -215,13 +236,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ransac_score: n_inl[cand][it] = pairs outside the sample whose reprojection error is < th.
+// k_ransac_score: n_inl[cand][it] = pairs outside the sample whose reprojection error is < th
+// (cv_rules: all pairs whose squared error is <= th^2).
 // One LANE per iteration: every lane builds the model of its own sample (no redundant work) and
 // walks the candidate's pairs, which all lanes read at the same address (an LDS broadcast).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kItersPerWg) void k_ransac_score(
     const double* __restrict__ pts_all, const int64_t* __restrict__ off, int n_iter,
-    const int32_t* __restrict__ samples, uint64_t seed, double th, int min_pairs,
+    const int32_t* __restrict__ samples, uint64_t seed, double th, int min_pairs, int cv_rules,
     int32_t* __restrict__ n_inl) {
   __shared__ double lpts[kLdsPairs * 4];
   const int64_t cand = blockIdx.x;
@@ -247,11 +269,20 @@ __global__ __launch_bounds__(kItersPerWg) void k_ransac_score(
   load_sample(pts, s, src, dst);
   homography4(src, dst, H);
   int cnt = 0;
-  for (int j = 0; j < n; ++j) {
-    const double* p = pts + (int64_t)j * 4;
-    const double e = reproj_error(H, p[0], p[1], p[2], p[3]);
-    const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
-    cnt += (!in_sample && e < th) ? 1 : 0;
+  if (cv_rules) {
+    // every pair counts, the sample's own included, at squared error <= th^2
+    const double th2 = th * th;
+    for (int j = 0; j < n; ++j) {
+      const double* p = pts + (int64_t)j * 4;
+      cnt += cv_sq_error(H, p[0], p[1], p[2], p[3]) <= th2 ? 1 : 0;
+    }
+  } else {
+    for (int j = 0; j < n; ++j) {
+      const double* p = pts + (int64_t)j * 4;
+      const double e = reproj_error(H, p[0], p[1], p[2], p[3]);
+      const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
+      cnt += (!in_sample && e < th) ? 1 : 0;
+    }
   }
   n_inl[cand * n_iter + it] = cnt;
 }
@@ -299,12 +330,220 @@ __device__ __forceinline__ void chol_solve9(const double* L, double* v) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The polish cv2.findHomography applies to the refitted model: Levenberg-Marquardt over the first
+// eight entries of H (H[8] = 1) on the inliers' reprojection residuals, at most ten steps, with
+// the damping schedule of OpenCV's LM solver (gain ratio above 0.75 halves the damping and drops
+// it to zero below a floor, below 0.25 multiplies it by a factor between 2 and 10).  One wave:
+// the sums over the inliers are wave reductions, the 8x8 solves are done by lane 0 in LDS.
+// ---------------------------------------------------------------------------------------------
+struct LmShared {
+  double A[64];    // J^T J
+  double Ap[64];   // damped copy, overwritten by its Cholesky factor
+  double v[8];     // J^T r
+  double d[8];     // step
+  double diag_inv; // largest diagonal entry of A^-1 (only when the damping restarts from zero)
+  int solved;
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+
+// residuals of the inliers at parameters h: S = sum r^2, rmax = max |r|; with `sh` also J^T J
+// and J^T r (written to LDS by lane 0, visible after the barrier this function ends with)
+__device__ void lm_residuals(const double* pts, const uint8_t* mask, int n, int lane,
+                             const double* h, LmShared* sh, double& S, double& rmax) {
+  double gg[6] = {0, 0, 0, 0, 0, 0};   // g g^T, g = (a, b, c):  aa ab ac bb bc cc
+  double gx[6] = {0, 0, 0, 0, 0, 0};   // xi * g (a, b)^T:       aa ab ba bb ca cb
+  double gy[6] = {0, 0, 0, 0, 0, 0};   // yi * g (a, b)^T
+  double qq[3] = {0, 0, 0};            // (xi^2 + yi^2) (a, b)(a, b)^T: aa ab bb
+  double jv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double s2 = 0, rm = 0;
+  for (int j = lane; j < n; j += 64) {
+    if (!mask[j]) continue;
+    const double* p = pts + (int64_t)j * 4;
+    const double x = p[0], y = p[1];
+    double ww = h[6] * x + h[7] * y + 1.0;
+    ww = fabs(ww) > 2.220446049250313e-16 ? 1.0 / ww : 0.0;
+    const double xi = (h[0] * x + h[1] * y + h[2]) * ww;
+    const double yi = (h[3] * x + h[4] * y + h[5]) * ww;
+    const double r1 = xi - p[2], r2 = yi - p[3];
+    s2 += r1 * r1 + r2 * r2;
+    rm = fmax(rm, fmax(fabs(r1), fabs(r2)));
+    if (sh) {
+      const double a = x * ww, b = y * ww, c = ww;
+      gg[0] += a * a; gg[1] += a * b; gg[2] += a * c; gg[3] += b * b; gg[4] += b * c; gg[5] += c * c;
+      gx[0] += xi * a * a; gx[1] += xi * a * b; gx[2] += xi * b * a; gx[3] += xi * b * b;
+      gx[4] += xi * c * a; gx[5] += xi * c * b;
+      gy[0] += yi * a * a; gy[1] += yi * a * b; gy[2] += yi * b * a; gy[3] += yi * b * b;
+      gy[4] += yi * c * a; gy[5] += yi * c * b;
+      const double q = xi * xi + yi * yi;
+      qq[0] += q * a * a; qq[1] += q * a * b; qq[2] += q * b * b;
+      jv[0] += a * r1; jv[1] += b * r1; jv[2] += c * r1;
+      jv[3] += a * r2; jv[4] += b * r2; jv[5] += c * r2;
+      const double t = xi * r1 + yi * r2;
+      jv[6] -= a * t; jv[7] -= b * t;
+    }
+  }
+  S = wave_sum(s2);
+  rmax = wave_max(rm);
+  if (!sh) return;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    gg[e] = wave_sum(gg[e]);
+    gx[e] = wave_sum(gx[e]);
+    gy[e] = wave_sum(gy[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) qq[e] = wave_sum(qq[e]);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) jv[e] = wave_sum(jv[e]);
+  __syncthreads();      // every lane is done with the previous A and v
+  if (lane == 0) {
+    double* A = sh->A;
+    for (int e = 0; e < 64; ++e) A[e] = 0.0;
+    const double g3[3][3] = {{gg[0], gg[1], gg[2]}, {gg[1], gg[3], gg[4]}, {gg[2], gg[4], gg[5]}};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        A[r * 8 + c] = g3[r][c];
+        A[(3 + r) * 8 + 3 + c] = g3[r][c];
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 2; ++c) {
+        A[r * 8 + 6 + c] = A[(6 + c) * 8 + r] = -gx[r * 2 + c];
+        A[(3 + r) * 8 + 6 + c] = A[(6 + c) * 8 + 3 + r] = -gy[r * 2 + c];
+      }
+    A[6 * 8 + 6] = qq[0];
+    A[6 * 8 + 7] = A[7 * 8 + 6] = qq[1];
+    A[7 * 8 + 7] = qq[2];
+    for (int e = 0; e < 8; ++e) sh->v[e] = jv[e];
+  }
+  __syncthreads();
+}
+
+// lane 0: Cholesky factor of the 8x8 matrix M (full storage, lower part used) in place; false
+// when a pivot is not positive
+__device__ bool chol8(double* M) {
+  for (int j = 0; j < 8; ++j) {
+    double d = M[j * 8 + j];
+    for (int k = 0; k < j; ++k) d -= M[j * 8 + k] * M[j * 8 + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    M[j * 8 + j] = d;
+    for (int i = j + 1; i < 8; ++i) {
+      double t = M[i * 8 + j];
+      for (int k = 0; k < j; ++k) t -= M[i * 8 + k] * M[j * 8 + k];
+      M[i * 8 + j] = t / d;
+    }
+  }
+  return true;
+}
+
+__device__ void chol8_solve(const double* L, double* b) {
+  for (int i = 0; i < 8; ++i) {
+    double t = b[i];
+    for (int k = 0; k < i; ++k) t -= L[i * 8 + k] * b[k];
+    b[i] = t / L[i * 8 + i];
+  }
+  for (int i = 7; i >= 0; --i) {
+    double t = b[i];
+    for (int k = i + 1; k < 8; ++k) t -= L[k * 8 + i] * b[k];
+    b[i] = t / L[i * 8 + i];
+  }
+}
+
+__device__ void lm_polish(const double* pts, const uint8_t* mask, int n, int lane, double* H,
+                          LmShared* sh) {
+  const double eps = 2.220446049250313e-16;
+  double x[8], xd[8], D[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = H[e];
+  double S, rmax;
+  lm_residuals(pts, mask, n, lane, x, sh, S, rmax);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) D[e] = sh->A[e * 8 + e];
+  double lambda = 1.0, lc = 0.75;
+#pragma unroll 1
+  for (int iter = 0; iter < 10;) {
+    if (lane == 0) {
+      for (int e = 0; e < 64; ++e) sh->Ap[e] = sh->A[e];
+      for (int e = 0; e < 8; ++e) {
+        sh->Ap[e * 8 + e] += lambda * D[e];
+        sh->d[e] = sh->v[e];
+      }
+      sh->solved = chol8(sh->Ap) ? 1 : 0;
+      if (sh->solved) chol8_solve(sh->Ap, sh->d);
+    }
+    __syncthreads();
+    if (!sh->solved) break;      // the damped normal equations are not positive definite
+    double d[8], dmax = 0, dv = 0, dS = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      d[e] = sh->d[e];
+      xd[e] = x[e] - d[e];
+      dmax = fmax(dmax, fabs(d[e]));
+      dv += d[e] * sh->v[e];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      double ad = 0;
+      for (int c = 0; c < 8; ++c) ad += sh->A[r * 8 + c] * d[c];
+      dS += d[r] * (2.0 * sh->v[r] - ad);
+    }
+    double Sd, rdmax;
+    lm_residuals(pts, mask, n, lane, xd, nullptr, Sd, rdmax);
+    const double R = (S - Sd) / (fabs(dS) > eps ? dS : 1.0);
+    if (R > 0.75) {
+      lambda *= 0.5;
+      if (lambda < lc) lambda = 0.0;
+    } else if (R < 0.25) {
+      double nu = (Sd - S) / (fabs(dv) > eps ? dv : 1.0) + 2.0;
+      nu = fmin(fmax(nu, 2.0), 10.0);
+      if (lambda == 0.0) {
+        __syncthreads();
+        if (lane == 0) {
+          for (int e = 0; e < 64; ++e) sh->Ap[e] = sh->A[e];
+          double mx = eps;
+          if (chol8(sh->Ap)) {
+            for (int c = 0; c < 8; ++c) {
+              double col[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+              col[c] = 1.0;
+              chol8_solve(sh->Ap, col);
+              mx = fmax(mx, fabs(col[c]));
+            }
+          }
+          sh->diag_inv = mx;
+        }
+        __syncthreads();
+        lambda = lc = 1.0 / sh->diag_inv;
+        nu *= 0.5;
+      }
+      lambda *= nu;
+    }
+    if (Sd < S) {
+      S = Sd;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = xd[e];
+      lm_residuals(pts, mask, n, lane, x, sh, S, rmax);
+    }
+    ++iter;
+    if (!(dmax >= eps && rmax >= eps)) break;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) H[e] = x[e];
+  H[8] = 1.0;
+}
+
 __global__ __launch_bounds__(64) void k_ransac_refit(
     const double* __restrict__ pts_all, const int64_t* __restrict__ off, int n_iter,
     const int32_t* __restrict__ samples, uint64_t seed, double th, int min_inliers,
-    int accept_mean_err, const int32_t* __restrict__ n_inl, double* __restrict__ H_out,
+    int flags, const int32_t* __restrict__ n_inl, double* __restrict__ H_out,
     int32_t* __restrict__ n_inliers, double* __restrict__ best_err, int32_t* __restrict__ best_it,
     uint8_t* __restrict__ mask_all) {
+  __shared__ LmShared lm_shared;
   const int64_t cand = blockIdx.x;
   const int64_t p0 = off[cand];
   const int n = (int)(off[cand + 1] - p0);
@@ -314,21 +553,57 @@ __global__ __launch_bounds__(64) void k_ransac_refit(
 
   const int min_pairs = min_inliers > 4 ? min_inliers : 4;
   bool ok = n >= min_pairs && n_iter > 0;
-  // first iteration with the largest count
+  const bool accept_mean_err = (flags & IC_RANSAC_MEAN_ERR) != 0;
+  const bool cv_rules = (flags & IC_RANSAC_CV_RULES) != 0;
   int bc = -1, bi = 0x7fffffff;
-  for (int it = lane; it < n_iter; it += 64) {
-    const int c = n_inl[cand * n_iter + it];
-    if (c > bc) {
-      bc = c;
-      bi = it;
+  if (!cv_rules) {
+    // first iteration with the largest count
+    for (int it = lane; it < n_iter; it += 64) {
+      const int c = n_inl[cand * n_iter + it];
+      if (c > bc) {
+        bc = c;
+        bi = it;
+      }
     }
-  }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const int oc = __shfl_xor(bc, o), oi = __shfl_xor(bi, o);
-    if (oc > bc || (oc == bc && oi < bi)) {
-      bc = oc;
-      bi = oi;
+    for (int o = 32; o >= 1; o >>= 1) {
+      const int oc = __shfl_xor(bc, o), oi = __shfl_xor(bi, o);
+      if (oc > bc || (oc == bc && oi < bi)) {
+        bc = oc;
+        bi = oi;
+      }
+    }
+  } else if (ok) {
+    // OpenCV's sequential loop, 64 iterations at a time.  A model is kept when it has strictly
+    // more inliers than every earlier one (and more than three); keeping it lowers the iteration
+    // limit to cv_num_iters(its count), and iteration it + 1 runs while it + 1 is below the limit
+    // in force after iteration it.  The limit only depends on the best count so far, so a prefix
+    // maximum over (count, earliest iteration) gives every lane the state the loop would have
+    // after its iteration, and the first lane whose successor would not run ends the search.
+    int64_t run_key = -1;
+    for (int c0 = 0; c0 < n_iter; c0 += 64) {
+      const int it = c0 + lane;
+      const int c = it < n_iter ? n_inl[cand * n_iter + it] : 0;
+      int64_t key = c > 3 ? (((int64_t)c << 32) | (int64_t)(0x7fffffff - it)) : -1;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int64_t other = __shfl_up(key, o);
+        if (lane >= o && other > key) key = other;
+      }
+      if (run_key > key) key = run_key;
+      const int best = key >= 0 ? (int)(key >> 32) : 0;
+      const int limit = best > 3 ? cv_num_iters(best, n, n_iter) : n_iter;
+      const bool last = it < n_iter && it + 1 >= limit;
+      const unsigned long long ends = __ballot(last);
+      const int src_lane = ends ? __builtin_ctzll(ends) : 63;
+      run_key = __shfl(key, src_lane);
+      if (ends) break;
+    }
+    if (run_key >= 0) {
+      bc = (int)(run_key >> 32);
+      bi = 0x7fffffff - (int)(run_key & 0x7fffffff);
+    } else {
+      ok = false;          // no sample gave a model with more than three inliers
     }
   }
 
@@ -341,12 +616,15 @@ __global__ __launch_bounds__(64) void k_ransac_refit(
     double src[8], dst[8], H4[9];
     load_sample(pts, s, src, dst);
     homography4(src, dst, H4);
-    // inlier flags (the sample itself always belongs to the consensus set) and centroids
+    // inlier flags (the reference's loop: the sample itself always belongs to the consensus
+    // set; OpenCV's rule: whatever lies within the threshold) and centroids
     double sx = 0, sy = 0, su = 0, sv = 0, sc = 0;
+    const double th2 = th * th;
     for (int j = lane; j < n; j += 64) {
       const double* p = pts + (int64_t)j * 4;
       const bool in_sample = j == s[0] || j == s[1] || j == s[2] || j == s[3];
-      const bool in = in_sample || reproj_error(H4, p[0], p[1], p[2], p[3]) < th;
+      const bool in = cv_rules ? cv_sq_error(H4, p[0], p[1], p[2], p[3]) <= th2
+                               : in_sample || reproj_error(H4, p[0], p[1], p[2], p[3]) < th;
       mask[j] = in ? 1 : 0;
       const double f = in ? 1.0 : 0.0;
       sx += f * p[0]; sy += f * p[1]; su += f * p[2]; sv += f * p[3]; sc += f;
@@ -441,6 +719,13 @@ __global__ __launch_bounds__(64) void k_ransac_refit(
       const double inv = 1.0 / H[8];
 #pragma unroll
       for (int e = 0; e < 9; ++e) H[e] *= inv;
+      if (cv_rules) {
+        bool finite = true;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) finite = finite && fabs(H[e]) < __builtin_inf();
+        if (finite) lm_polish(pts, mask, n, lane, H, &lm_shared);
+        else ok = false;
+      }
       double es = 0;
       for (int j = lane; j < n; j += 64) {
         const double* p = pts + (int64_t)j * 4;
@@ -478,15 +763,15 @@ hipError_t launch_compact_matches(const uint8_t* mask, const int32_t* i1, const 
 
 hipError_t launch_ransac(const double* pts, const int64_t* off, int64_t n_cand, int n_iter,
                          const int32_t* samples, uint64_t seed, double th, int min_inliers,
-                         int accept_mean_err, int32_t* n_inl_ws, double* H, int32_t* n_inliers,
+                         int flags, int32_t* n_inl_ws, double* H, int32_t* n_inliers,
                          double* best_err, int32_t* best_it, uint8_t* mask, hipStream_t s) {
   if (n_iter > 0) {
     const dim3 grid((unsigned)n_cand, (unsigned)((n_iter + kItersPerWg - 1) / kItersPerWg));
     hipLaunchKernelGGL(k_ransac_score, grid, dim3(kItersPerWg), 0, s, pts, off, n_iter, samples, seed, th,
-                       min_inliers > 4 ? min_inliers : 4, n_inl_ws);
+                       min_inliers > 4 ? min_inliers : 4, (flags & IC_RANSAC_CV_RULES) != 0, n_inl_ws);
   }
   hipLaunchKernelGGL(k_ransac_refit, dim3((unsigned)n_cand), dim3(64), 0, s, pts, off, n_iter,
-                     samples, seed, th, min_inliers, accept_mean_err, n_inl_ws, H, n_inliers,
+                     samples, seed, th, min_inliers, flags, n_inl_ws, H, n_inliers,
                      best_err, best_it, mask);
   return hipGetLastError();
 }

@@ -800,8 +800,12 @@ def compact_matches(mask, i1, row_offsets, kp_query=None, kp_rows=None):
 
 
 def ransac_homography(pts, offsets, n_iter, th, samples=None, seed=0, min_inliers=10,
-                      accept_mean_err=True):
+                      accept_mean_err=True, cv_rules=False):
     """Homography RANSAC for every candidate's matched pairs at once.
+
+    cv_rules=False: the reference's own ransac() loop; cv_rules=True: the loop of
+    cv2.findHomography(..., cv2.RANSAC, th) (inliers at squared error <= th^2, adaptive iteration
+    limit at confidence 0.995 starting from n_iter, refit over the inliers + LM polish).
 
     pts float64 [total, 4], offsets int64 [n_cand + 1] (device), samples int32
     [n_cand, n_iter, 4] or None.  Returns (H float64 [n_cand, 3, 3], n_inliers int32 [n_cand],
@@ -824,7 +828,8 @@ def ransac_homography(pts, offsets, n_iter, th, samples=None, seed=0, min_inlier
     mask = torch.zeros(pts.shape[0], dtype=torch.uint8, device=pts.device)
     rc = _lib.load().ic_ransac_homography(
         _lib.handle(dev), _ptr(pts), _ptr(offsets.contiguous()), n_cand, n_iter, _ptr(samples),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, float(th), int(min_inliers), 1 if accept_mean_err else 0,
+        int(seed) & 0xFFFFFFFFFFFFFFFF, float(th), int(min_inliers),
+        (1 if accept_mean_err else 0) | (2 if cv_rules else 0),
         _ptr(H), _ptr(n_inl), _ptr(err), _ptr(best_it), _ptr(mask), _stream_ptr(dev))
     _lib.check(rc, "ic_ransac_homography")
     return H, n_inl, err, best_it, mask

@@ -13,8 +13,11 @@ RANSAC variants (`ransac_algorithm`): any value other than cv2.RANSAC (8) select
 own `ransac()` (:291-365): int(log(1-prob)/log(1-inlier_r^4)) iterations capped by
 `ransac_max_iter`, at least MIN_INLIERS_TH = 10 inliers and a mean reprojection error within
 `ransac_th`.  The default 8 stands for cv2.findHomography(..., cv2.RANSAC, ransac_th); OpenCV is
-not used here, the same device kernels run with OpenCV's published defaults instead (2000
-iterations, at least 4 inliers, no mean-error rule).  Samples come from a counter-based generator
+not used here, the device kernels follow that function's published loop instead (inliers at
+squared error <= ransac_th^2, a model kept when it has strictly more inliers than every earlier
+one, the iteration limit lowered from 2000 at confidence 0.995 with every kept model, refit over
+the inliers and a Levenberg-Marquardt polish; the mask is the kept minimal model's).  No OpenCV
+output exists to pin this against.  Samples come from a counter-based generator
 on the device, seeded per call from numpy's global generator (so `np.random.seed` makes a run
 repeatable, as it does for the reference's `np.random.shuffle`).  A `homography_fn`
 callable `(q_points [m,2], im_points [m,2]) -> (H, mask)` replaces the device RANSAC per
@@ -98,10 +101,11 @@ class RobustMatcher(object):
         return out
 
     def _ransac_params(self):
+        """(iteration limit, fewest inliers, mean-error rule, OpenCV's loop rules)"""
         if self.ransac_algorithm == CV_RANSAC:
-            return CV_RANSAC_MAX_ITERS, 4, False
+            return CV_RANSAC_MAX_ITERS, 4, False, True
         return (ransac_num_iterations(self.ransac_max_iter, self.ransac_prob, self.inlier_r),
-                MIN_INLIERS_TH, True)
+                MIN_INLIERS_TH, True, False)
 
     def match_and_verify(self, query, image_list):
         """The whole of `match` on the device.  Returns one dict per candidate with `n_matches`,
@@ -127,10 +131,11 @@ class RobustMatcher(object):
         kp_rows = b.f64(np.ascontiguousarray(np.concatenate(kps)))
         kp_q = b.f64(np.ascontiguousarray(np.asarray(query.keypoints, dtype=np.float64).reshape(-1, 2)))
         out_off, match_q, match_im, pts = b.compact_matches(mask, i1, b.i64(rows), kp_q, kp_rows)
-        n_iter, min_inliers, mean_rule = self._ransac_params()
+        n_iter, min_inliers, mean_rule, cv_rules = self._ransac_params()
         seed = int(np.random.randint(0, 2 ** 31 - 1))
         _H, n_inl, _err, _it, in_mask = b.ransac_homography(
-            pts, out_off, n_iter, float(self.ransac_th), None, seed, min_inliers, mean_rule)
+            pts, out_off, n_iter, float(self.ransac_th), None, seed, min_inliers, mean_rule,
+            cv_rules)
         out_off = out_off.cpu().numpy()
         n_inl = n_inl.cpu().numpy()
         total = int(out_off[-1])
@@ -204,13 +209,13 @@ class RobustMatcher(object):
                                               axis=1))
         saved, self.ransac_algorithm = self.ransac_algorithm, opt
         try:
-            n_iter, min_inliers, mean_rule = self._ransac_params()
+            n_iter, min_inliers, mean_rule, cv_rules = self._ransac_params()
         finally:
             self.ransac_algorithm = saved
         seed = int(np.random.randint(0, 2 ** 31 - 1))
         H, n_inl, _err, _it, mask = b.ransac_homography(
             b.f64(data), b.i64([0, data.shape[0]]), n_iter, float(self.ransac_th), None, seed,
-            min_inliers, mean_rule)
+            min_inliers, mean_rule, cv_rules)
         homography = H[0].cpu().numpy() if int(n_inl[0]) > 0 else None
         return homography, mask.cpu().numpy().reshape(-1, 1)
 

@@ -249,12 +249,21 @@ int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
                        int32_t* match_q, int32_t* match_im, double* pts, void* stream);
 
 /* Homography RANSAC over the matched pairs of every candidate image at once.  Replaces
- * RobustMatcher._robust_h_estimation -> ransac(data, HomographyModel, 4, ...)
- * (model/robust_matching.py:196-225, :291-365): per iteration a homography through four sampled
- * pairs, inliers = other pairs with reprojection error (HomographyModel.get_error, :259-283)
- * below th; the first iteration with the most inliers is refitted over sample + inliers by the
- * direct linear transform and kept when it has at least min_inliers pairs and (accept_mean_err
- * != 0) a mean reprojection error <= th, as :359-363 demands.
+ * RobustMatcher._robust_h_estimation (model/robust_matching.py:196-225) in both of its forms,
+ * chosen by `flags`:
+ *  - without IC_RANSAC_CV_RULES, the reference's own ransac(data, HomographyModel, 4, ...)
+ *    (:291-365): per iteration a homography through four sampled pairs, inliers = other pairs
+ *    with reprojection error (HomographyModel.get_error, :259-283) below th; the first iteration
+ *    with the most inliers is refitted over sample + inliers by the direct linear transform and
+ *    kept when it has at least min_inliers pairs and (IC_RANSAC_MEAN_ERR) a mean reprojection
+ *    error <= th, as :359-363 demands; all n_iter iterations count.
+ *  - with IC_RANSAC_CV_RULES, the published loop of cv2.findHomography(src, dst, cv2.RANSAC, th),
+ *    the reference's default (:214-216): every pair whose squared error is <= th^2 is an inlier
+ *    (the sample gets no special treatment), a model is kept when it has strictly more inliers
+ *    than every earlier one and more than three, every kept model lowers the iteration limit to
+ *    log(1 - 0.995) / log(1 - (inliers / pairs)^4) (n_iter is the initial limit, OpenCV's is
+ *    2000), the mask is the kept minimal model's, and H is refitted over those inliers and
+ *    polished by at most ten Levenberg-Marquardt steps.  best_iter is the kept iteration.
  *   pts [total][4] float64 (x_src, y_src, x_dst, y_dst), offsets [n_cand+1] int64 (device),
  *   samples [n_cand][n_iter][4] int32 pair indices inside the candidate, or NULL to draw them
  *   from a counter-based generator seeded with `seed`;
@@ -262,9 +271,11 @@ int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
  *   best_err [n_cand] float64, best_iter [n_cand] int32 or NULL, inlier_mask [total] uint8.
  * Candidates with fewer than max(4, min_inliers) pairs can never be accepted and are rejected
  * without scoring (best_iter -1, best_err +inf). */
+#define IC_RANSAC_MEAN_ERR 1
+#define IC_RANSAC_CV_RULES 2
 int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets, int64_t n_cand,
                          int n_iter, const int32_t* samples, uint64_t seed, double th,
-                         int min_inliers, int accept_mean_err, double* H, int32_t* n_inliers,
+                         int min_inliers, int flags, double* H, int32_t* n_inliers,
                          double* best_err, int32_t* best_iter, uint8_t* inlier_mask, void* stream);
 
 /* Host-side helper of the upload path; touches no GPU and needs no handle.  Replaces the

@@ -9,11 +9,21 @@ both point sets (centroid, mean absolute deviation per axis), the 9x9 matrix L^T
 direct linear transform, its eigenvector of the smallest eigenvalue, denormalisation, H[2,2] = 1.
 For exactly four points that is the unique homography; for more points the value OpenCV would
 return differs by the polish step, and that difference is unpinned.
+
+The reference's DEFAULT is not its own loop but cv2.findHomography(q, im, cv2.RANSAC, th)
+(model/robust_matching.py:214-216).  `cv_find_homography_ransac` restates the published algorithm
+of that call (OpenCV 4, modules/calib3d: RANSACPointSetRegistrator::run, RANSACUpdateNumIters,
+HomographyEstimatorCallback::computeError, HomographyRefineCallback, LMSolverImpl::run) from its
+documentation and source as remembered; no OpenCV is installed and the reference holds no output
+of it, so this part is PARITY UNPINNED.  Known departures: errors are evaluated in float64
+(OpenCV: float32 points and errors); samples come from the caller (OpenCV: its own generator,
+re-drawing samples with three collinear points).
 """
 import numpy as np
 
 __all__ = ["HomographyModel", "ransac", "random_partition", "ransac_num_iterations",
-           "MIN_INLIERS_TH"]
+           "MIN_INLIERS_TH", "cv_update_num_iters", "cv_sq_error", "cv_lm_refine",
+           "cv_find_homography_ransac"]
 
 MIN_INLIERS_TH = 10   # model/robust_matching.py:13
 
@@ -116,3 +126,152 @@ def ransac(data, model, min_model_points, max_iter, th, p=0.95, w=0.5, rng=np.ra
     else:
         best_fit = None
     return best_fit, mask, best_err
+
+
+# ---------------------------------------------------------------------------------------------
+# cv2.findHomography(..., cv2.RANSAC, th): the reference's default (model/robust_matching.py:214)
+# ---------------------------------------------------------------------------------------------
+CV_CONFIDENCE = 0.995
+CV_MAX_ITERS = 2000
+_DBL_MIN = np.finfo(np.float64).tiny
+_DBL_EPS = np.finfo(np.float64).eps
+
+
+def cv_update_num_iters(p, ep, model_points, max_iters):
+    """RANSACUpdateNumIters: iterations after which a sample free of outliers has been drawn with
+    probability p when a fraction ep of the data are outliers, never more than max_iters."""
+    p = min(max(p, 0.0), 1.0)
+    ep = min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, _DBL_MIN)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < _DBL_MIN:
+        return 0
+    num, denom = np.log(num), np.log(denom)
+    if denom >= 0 or -num >= max_iters * (-denom):
+        return max_iters
+    return int(np.rint(num / denom))        # cvRound: to nearest, ties to even
+
+
+def cv_sq_error(data, H):
+    """HomographyEstimatorCallback::computeError: squared distance between the projected source
+    point and the destination point (H[2,2] = 1)."""
+    data = np.asarray(data, dtype=np.float64)
+    h = np.asarray(H, dtype=np.float64).reshape(9)
+    x, y, u, v = data[:, 0], data[:, 1], data[:, 2], data[:, 3]
+    with np.errstate(all="ignore"):
+        ww = 1.0 / (h[6] * x + h[7] * y + 1.0)
+        dx = (h[0] * x + h[1] * y + h[2]) * ww - u
+        dy = (h[3] * x + h[4] * y + h[5]) * ww - v
+        return dx * dx + dy * dy
+
+
+def _refine_residuals(h8, data, want_jac):
+    x, y, u, v = data[:, 0], data[:, 1], data[:, 2], data[:, 3]
+    ww = h8[6] * x + h8[7] * y + 1.0
+    ww = np.where(np.abs(ww) > _DBL_EPS, 1.0 / np.where(ww == 0, 1.0, ww), 0.0)
+    xi = (h8[0] * x + h8[1] * y + h8[2]) * ww
+    yi = (h8[3] * x + h8[4] * y + h8[5]) * ww
+    n = data.shape[0]
+    r = np.empty(2 * n)
+    r[0::2], r[1::2] = xi - u, yi - v
+    if not want_jac:
+        return r, None
+    J = np.zeros((2 * n, 8))
+    J[0::2, 0], J[0::2, 1], J[0::2, 2] = x * ww, y * ww, ww
+    J[0::2, 6], J[0::2, 7] = -x * ww * xi, -y * ww * xi
+    J[1::2, 3], J[1::2, 4], J[1::2, 5] = x * ww, y * ww, ww
+    J[1::2, 6], J[1::2, 7] = -x * ww * yi, -y * ww * yi
+    return r, J
+
+
+def cv_lm_refine(H, data, max_iters=10):
+    """The polish findHomography applies to the refitted model: Levenberg-Marquardt over the first
+    eight entries of H on the inliers' reprojection residuals (HomographyRefineCallback,
+    LMSolverImpl::run with maxIters = 10, epsx = epsf = DBL_EPSILON)."""
+    data = np.asarray(data, dtype=np.float64)
+    x = np.asarray(H, dtype=np.float64).reshape(9)[:8].copy()
+    r, J = _refine_residuals(x, data, True)
+    S = float(r.dot(r))
+    A, v = J.T.dot(J), J.T.dot(r)
+    D = np.diag(A).copy()
+    r_lo, r_hi = 0.25, 0.75
+    lam, lc = 1.0, 0.75
+    it = 0
+    while True:
+        Ap = A + np.diag(lam * D)
+        try:
+            d = np.linalg.solve(Ap, v)
+        except np.linalg.LinAlgError:
+            d = np.linalg.lstsq(Ap, v, rcond=None)[0]
+        xd = x - d
+        rd, _ = _refine_residuals(xd, data, False)
+        Sd = float(rd.dot(rd))
+        dS = float(d.dot(2.0 * v - A.dot(d)))
+        R = (S - Sd) / (dS if abs(dS) > _DBL_EPS else 1.0)
+        if R > r_hi:
+            lam *= 0.5
+            if lam < lc:
+                lam = 0.0
+        elif R < r_lo:
+            t = float(d.dot(v))
+            nu = (Sd - S) / (t if abs(t) > _DBL_EPS else 1.0) + 2.0
+            nu = min(max(nu, 2.0), 10.0)
+            if lam == 0:
+                inv = np.linalg.pinv(A)
+                maxval = max(_DBL_EPS, float(np.abs(np.diag(inv)).max()))
+                lam = lc = 1.0 / maxval
+                nu *= 0.5
+            lam *= nu
+        if Sd < S:
+            S, x = Sd, xd
+            r, J = _refine_residuals(x, data, True)
+            A, v = J.T.dot(J), J.T.dot(r)
+        it += 1
+        if not (it < max_iters and np.abs(d).max() >= _DBL_EPS and np.abs(r).max() >= _DBL_EPS):
+            break
+    return np.append(x, 1.0).reshape(3, 3)
+
+
+def cv_find_homography_ransac(data, th, samples, max_iters=CV_MAX_ITERS, confidence=CV_CONFIDENCE,
+                              polish=True, info=None):
+    """cv2.findHomography(src, dst, cv2.RANSAC, th) on rows (x_src, y_src, x_dst, y_dst), with the
+    four-point samples given: samples[it] are the pair indices of iteration `it`.
+
+    The loop of RANSACPointSetRegistrator::run: every iteration fits the sample's homography,
+    counts the pairs (all of them, the sample included) whose squared error is <= th^2, keeps the
+    model when it has strictly more inliers than the best so far (and more than three), and then
+    lowers the iteration limit to cv_update_num_iters(confidence, outlier fraction).  Afterwards
+    findHomography refits over the kept model's inliers (normalised DLT) and polishes the result;
+    the mask it returns is the kept minimal model's.  Returns (H or None, mask int [n]);
+    info receives best_it and the number of iterations the loop ran.
+    """
+    data = np.asarray(data, dtype=np.float64)
+    n = data.shape[0]
+    mask = np.zeros(n, dtype=int)
+    if info is not None:
+        info["best_it"], info["iterations"] = -1, 0
+    if n < 4:
+        return None, mask
+    niters = min(max_iters, len(samples))
+    best_count, best_mask, best_it = 0, None, -1
+    it = 0
+    while it < niters:
+        model = HomographyModel.fit(data[np.asarray(samples[it])])
+        if model is not None and np.isfinite(model).all():
+            inl = cv_sq_error(data, model) <= th * th
+            good = int(inl.sum())
+            if good > max(best_count, 3):
+                best_count, best_mask, best_it = good, inl, it
+                niters = cv_update_num_iters(confidence, (n - good) / float(n), 4, niters)
+        it += 1
+    if info is not None:
+        info["best_it"], info["iterations"] = best_it, it
+    if best_mask is None:
+        return None, mask
+    mask[best_mask] = 1
+    H = HomographyModel.fit(data[best_mask])
+    if H is None or not np.isfinite(H).all():
+        return None, np.zeros(n, dtype=int)
+    if polish:
+        H = cv_lm_refine(H, data[best_mask])
+    return H, mask

@@ -180,7 +180,7 @@ class CheckerBackend(object):
                 None if pts is None else torch.from_numpy(pts))
 
     def ransac_homography(self, pts, offsets, n_iter, th, samples=None, seed=0, min_inliers=10,
-                          accept_mean_err=True):
+                          accept_mean_err=True, cv_rules=False):
         from oracle import ransac_ref
         off = offsets.numpy()
         n_cand = len(off) - 1
@@ -203,9 +203,17 @@ class CheckerBackend(object):
                 rng = np.random.RandomState((int(seed) + 7919 * c) % (2 ** 32))
                 parts = [ransac_ref.random_partition(4, n, rng) for _ in range(n_iter)]
             info = {}
-            fit, m, e = ransac_ref.ransac(data, ransac_ref.HomographyModel, 4, 0, th,
-                                          partitions=parts, num_it=n_iter, min_inliers=min_inliers,
-                                          accept_mean_err=accept_mean_err, info=info)
+            if cv_rules:
+                fit, m = ransac_ref.cv_find_homography_ransac(
+                    data, th, [p_[0] for p_ in parts], max_iters=n_iter, info=info)
+                e = np.inf if fit is None else \
+                    float(ransac_ref.HomographyModel.get_error(data[m.astype(bool)], fit).mean())
+                if fit is not None and m.sum() < min_inliers:
+                    fit, m = None, np.zeros_like(m)
+            else:
+                fit, m, e = ransac_ref.ransac(
+                    data, ransac_ref.HomographyModel, 4, 0, th, partitions=parts, num_it=n_iter,
+                    min_inliers=min_inliers, accept_mean_err=accept_mean_err, info=info)
             err[c] = e
             best_it[c] = info["best_it"]
             if fit is not None:

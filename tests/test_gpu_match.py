@@ -121,10 +121,68 @@ def test_ransac_same_samples_as_reference_loop():
         assert (got & ~truths[c]).sum() <= 2 and (got & truths[c]).sum() >= 0.8 * truths[c].sum()
 
 
-def test_ransac_opencv_style_rule_and_many_iterations():
+def test_ransac_without_the_mean_error_rule_and_many_iterations():
     rng = np.random.default_rng(12)
     cands = [_planted(rng, n, f)[0] for n, f in [(50, 0.3), (8, 1.0), (20, 0.25)]]
     _run_case(cands, 200, 2.0, seed=9, min_inliers=4, mean_rule=False)
+
+
+def _cv_case(cands, n_iter, th, seed):
+    """Device loop with OpenCV's rules against its restatement, same samples on both sides."""
+    rng = np.random.RandomState(seed)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in cands])]).astype(np.int64)
+    pts = np.ascontiguousarray(np.concatenate(cands))
+    samples = np.zeros((len(cands), n_iter, 4), dtype=np.int32)
+    for c, data in enumerate(cands):
+        if len(data) >= 4:
+            for it in range(n_iter):
+                samples[c, it] = rng.permutation(len(data))[:4]
+    H, n_inl, err, best_it, mask = ops.ransac_homography(
+        torch.from_numpy(pts).cuda(), torch.from_numpy(off).cuda(), n_iter, th,
+        torch.from_numpy(samples).cuda(), 0, 4, False, cv_rules=True)
+    H, n_inl, err, best_it, mask = (t.cpu().numpy() for t in (H, n_inl, err, best_it, mask))
+    ran = []
+    for c, data in enumerate(cands):
+        got_mask = mask[off[c]:off[c + 1]]
+        info = {}
+        fit, ref_mask = ransac_ref.cv_find_homography_ransac(data, th, samples[c],
+                                                             max_iters=n_iter, info=info)
+        ran.append(info["iterations"])
+        assert best_it[c] == info["best_it"], "candidate %d kept another iteration" % c
+        assert np.array_equal(got_mask.astype(int), ref_mask), "candidate %d inlier mask" % c
+        assert n_inl[c] == ref_mask.sum()
+        if fit is not None:
+            assert np.abs(H[c] - fit).max() <= 1e-6 * np.abs(fit).max(), "candidate %d" % c
+            # the polish does not make the fit worse than the plain refit over the inliers
+            inl = data[ref_mask.astype(bool)]
+            plain, _ = ransac_ref.cv_find_homography_ransac(data, th, samples[c],
+                                                            max_iters=n_iter, polish=False)
+            assert ransac_ref.cv_sq_error(inl, H[c]).sum() <= \
+                ransac_ref.cv_sq_error(inl, plain).sum() * (1 + 1e-9)
+        else:
+            assert not H[c].any() and n_inl[c] == 0
+    return n_inl, mask, off, ran
+
+
+def test_ransac_opencv_rules_same_samples_as_the_restated_loop():
+    rng = np.random.default_rng(21)
+    specs = [(60, 0.7), (4, 1.0), (3, 1.0), (12, 1.0), (300, 0.4), (40, 0.0), (25, 0.5),
+             (9, 1.0), (130, 0.9), (500, 0.15), (64, 0.3), (5, 0.8)]
+    built = [_planted(rng, n, f) for n, f in specs]
+    cands = [b[0] for b in built]
+    n_inl, mask, off, ran = _cv_case(cands, 2000, 3.0, seed=3)
+    # the iteration limit adapts: mostly-inlier candidates stop after a handful of samples, a
+    # candidate without structure runs to the end
+    assert ran[0] < 40 and ran[8] < 10 and ran[3] <= 5 and ran[5] == 2000
+    assert n_inl[2] == 0                      # three pairs: no model
+    assert n_inl[1] == 4 and n_inl[3] == 12   # exact fits keep every pair
+    for c in (0, 4, 8):     # (15 % inliers need more than 2000 samples to be found reliably)
+        truth = built[c][1]
+        got = mask[off[c]:off[c + 1]].astype(bool)
+        assert (got & truth).sum() >= 0.85 * truth.sum() and (got & ~truth).sum() <= 3
+    # a tight threshold (the logo pipeline's 0.5) and few iterations
+    _cv_case(cands, 64, 0.5, seed=4)
+    _cv_case(cands[:3], 1, 3.0, seed=5)
 
 
 def test_ransac_device_generated_samples():
