@@ -41,7 +41,7 @@ hipError_t assign_init();
 // multiple of 128), whose mean vector does not fit in front and lies behind the norms:
 constexpr int kAuxCnMax = 128;    // [0, 128) mean vector m (D = 128); [128] max_j |c_j - m|^2
 constexpr int kAuxCr2Max = 129;   // [129] max_j |c_j|^2
-constexpr int kAuxNorms = 256;    // [256 + j] = |c_j - m|^2 for j < k, +inf for k <= j < kpad
+constexpr int kAuxNorms = 256;    // [256 + j] = |c_j - m|^2 for j < k, 3.2e38 for k <= j < kpad
 constexpr int kMaxWideD = 2048;   // widest (padded) row the search handles
 inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? kAuxNorms + kpad : 0; }
 inline int64_t aux_floats(int64_t kpad, int D) { return kAuxNorms + kpad + (D > kD ? D : 0); }
