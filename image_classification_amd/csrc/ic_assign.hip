@@ -486,7 +486,9 @@ __host__ __device__ __forceinline__ int tail_pieces(const TailGeom& t, int64_t t
 #ifdef IC_TRACE
 // Timeline instrumentation of the search kernel (tools/wgtrace.py; built as a separate library by
 // `make trace`, never part of libic_hip.so): per workgroup the 100 MHz wall clock at entry, at the
-// first barrier, at the first change of row tile (before / after) and at exit, and where it ran.
+// first barrier, when its first rows had landed and were centred (a workgroup that goes on to
+// another row tile overwrites these two with the time before / after that change), at exit, and
+// where it ran.
 constexpr int kTraceWgs = 1 << 16;
 __device__ unsigned long long ic_trace_buf[kTraceWgs][8];
 #define IC_TRACE_PUT(slot, value)                                                         \
@@ -592,6 +594,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (first) IC_TRACE_NOW(4);
     // centre the rows on the codebook mean and scale by -2 (exact); on the way, this lane's half
     // of |x - m|^2 and of (x - m).m for the band
     float xr[1][64];
@@ -640,6 +643,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
       gate[0] = start;
     }
 
+    if (first) IC_TRACE_NOW(5);
     if (first) {
       // the first stage has landed once at most the second one's loads are outstanding
       if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMinLoads) : "memory");

@@ -537,13 +537,16 @@ __device__ void lm_polish(const double* pts, const uint8_t* mask, int n, int lan
   H[8] = 1.0;
 }
 
+// CV: OpenCV's rules (adaptive iteration limit, squared-error inliers, LM polish); otherwise the
+// reference's own loop.  Two instantiations, so that the plain loop does not carry the polish's
+// registers and LDS.
+template <bool CV>
 __global__ __launch_bounds__(64) void k_ransac_refit(
     const double* __restrict__ pts_all, const int64_t* __restrict__ off, int n_iter,
     const int32_t* __restrict__ samples, uint64_t seed, double th, int min_inliers,
     int flags, const int32_t* __restrict__ n_inl, double* __restrict__ H_out,
     int32_t* __restrict__ n_inliers, double* __restrict__ best_err, int32_t* __restrict__ best_it,
     uint8_t* __restrict__ mask_all) {
-  __shared__ LmShared lm_shared;
   const int64_t cand = blockIdx.x;
   const int64_t p0 = off[cand];
   const int n = (int)(off[cand + 1] - p0);
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(64) void k_ransac_refit(
   const int min_pairs = min_inliers > 4 ? min_inliers : 4;
   bool ok = n >= min_pairs && n_iter > 0;
   const bool accept_mean_err = (flags & IC_RANSAC_MEAN_ERR) != 0;
-  const bool cv_rules = (flags & IC_RANSAC_CV_RULES) != 0;
+  constexpr bool cv_rules = CV;
   int bc = -1, bi = 0x7fffffff;
   if (!cv_rules) {
     // first iteration with the largest count
@@ -719,7 +722,8 @@ __global__ __launch_bounds__(64) void k_ransac_refit(
       const double inv = 1.0 / H[8];
 #pragma unroll
       for (int e = 0; e < 9; ++e) H[e] *= inv;
-      if (cv_rules) {
+      if constexpr (CV) {
+        __shared__ LmShared lm_shared;
         bool finite = true;
 #pragma unroll
         for (int e = 0; e < 9; ++e) finite = finite && fabs(H[e]) < __builtin_inf();
@@ -770,7 +774,8 @@ hipError_t launch_ransac(const double* pts, const int64_t* off, int64_t n_cand, 
     hipLaunchKernelGGL(k_ransac_score, grid, dim3(kItersPerWg), 0, s, pts, off, n_iter, samples, seed, th,
                        min_inliers > 4 ? min_inliers : 4, (flags & IC_RANSAC_CV_RULES) != 0, n_inl_ws);
   }
-  hipLaunchKernelGGL(k_ransac_refit, dim3((unsigned)n_cand), dim3(64), 0, s, pts, off, n_iter,
+  auto refit = (flags & IC_RANSAC_CV_RULES) ? k_ransac_refit<true> : k_ransac_refit<false>;
+  hipLaunchKernelGGL(refit, dim3((unsigned)n_cand), dim3(64), 0, s, pts, off, n_iter,
                      samples, seed, th, min_inliers, flags, n_inl_ws, H, n_inliers,
                      best_err, best_it, mask);
   return hipGetLastError();

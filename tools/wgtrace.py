@@ -2,7 +2,8 @@
 """Timeline of the search kernel's workgroups: wgtrace.py N K  (needs `make trace` in csrc/).
 
 Runs one search with the instrumented library and prints, per CU, when each of its workgroups
-entered, passed its first barrier, changed row tile and left (microseconds from the first entry)."""
+entered, passed its first barrier, had its rows in registers and centred (or, with several row
+tiles, changed row tile) and left (microseconds from the first entry)."""
 import ctypes
 import os
 import sys
@@ -57,7 +58,7 @@ def main():
           % (np.median(cyc), cyc.min(), cyc.max()))
     if np.isfinite(sw0).any():
         d = sw1 - sw0
-        print("row-tile change (store lists, load + centre rows): median %.1f  max %.1f us, %d workgroups"
+        print("rows landed -> centred (workgroups with several row tiles: the change of row tile): median %.1f  max %.1f us, %d workgroups"
               % (np.nanmedian(d), np.nanmax(d), int(np.isfinite(d).sum())))
     per_cu = {}
     for i in range(len(t)):
@@ -68,7 +69,7 @@ def main():
     for pl, evs in busiest:
         print("CU %d:" % pl)
         for e in sorted(evs):
-            print("   entry %7.1f  barrier %7.1f  change %7.1f..%7.1f  exit %7.1f" % e)
+            print("   entry %7.1f  barrier %7.1f  rows landed / centred %7.1f..%7.1f  exit %7.1f" % e)
     ends = np.array([max(e[-1] for e in v) for v in per_cu.values()])
     print("per-CU last exit: min %.1f  median %.1f  max %.1f" % (ends.min(), np.median(ends), ends.max()))
 
