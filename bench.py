@@ -125,7 +125,9 @@ def launch_ranks(n_ranks, argv):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    # default: some seconds of device work, so that a coarse utilisation sampler running beside
+    # the bench sees it (20 steps of the default workload are over in 0.36 s)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bow")
     ap.add_argument("--codebook", type=int, default=0,
