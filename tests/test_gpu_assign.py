@@ -329,18 +329,26 @@ def test_gathered_parts_path_equals_device_path():
     parts = [sift_like(s, seed=100 + i) if s else np.empty((0, 128), np.float32)
              for i, s in enumerate(sizes)]
     parts[3] = parts[3].astype(np.float64)
+    # what the native gather does not read as it is (strided views, Fortran order, half floats,
+    # integers) is converted first, and the caller's list is left alone
+    parts[5] = np.ascontiguousarray(np.repeat(parts[5], 2, axis=0))[::2]
+    parts[7] = np.asfortranarray(parts[7])
+    parts[9] = np.round(parts[9]).astype(np.uint8)
+    parts[11] = parts[11].astype(np.float16)
+    kept = list(parts)
     c = sift_like(600, seed=63)
     cd = _dev(c)
     cn = ops.codebook_aux(cd)
     allx = np.concatenate([p.astype(np.float32) for p in parts])
     ref = ops.assign_top2(_dev(allx), cd, 0.8, cn)
-    for chunk in (50_000, 131_072):
+    for chunk in (1000, 50_000, 131_072):
         got = ops.assign_from_host_parts(parts, cd, cn, top2=True, ratio=0.8, chunk_rows=chunk)
         torch.cuda.synchronize()
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
     idx, dist = ops.assign_from_host_parts(parts, cd, cn, top2=False, want_dist=False)
     assert dist is None and torch.equal(idx, ref[0])
+    assert all(a is b for a, b in zip(parts, kept))
     with pytest.raises(ValueError):
         ops.assign_from_host_parts([np.zeros((3, 64), np.float32)], cd, cn)
 
