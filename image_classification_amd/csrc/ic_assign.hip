@@ -1222,29 +1222,40 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     return row >= split_row0 ? 2 * tail_pieces(tail, (row - split_row0) / tail.rows_per_wg) : 2;
   };
 
-  // one row, by the 16 lanes of a group; a row that needs the direct search is put on the list
-  auto full_look = [&](int64_t row) {
-    // the row itself does not depend on the lists: its loads go out first and travel together
-    // with theirs
-    const float* xrow = X + row * (int64_t)(WIDE ? D : kD) + sub * 8;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + 4);
-    ic_top2_rec b = pb.rec[row];
-    float v3 = pb.d3[row];
+  // What the lists of a row say once merged: the two best (value, index) pairs; v3, the third
+  // smallest value over all lists; u3, the smallest value a list holds without its index (the
+  // third of a list, the fourth when the search kept three indices), i.e. the best candidate
+  // whose INDEX no record holds.
+  struct Head {
+    ic_top2_rec b;
+    float v3, u3;
+  };
+  const float* __restrict__ unnamed = mode2 ? pb.d4 : pb.d3;
+  auto merge_lists = [&](int64_t row) {
+    Head hd;
+    hd.b = pb.rec[row];
+    hd.v3 = pb.d3[row];
+    hd.u3 = unnamed[row];
     const int ns = n_lists(row);
-    // v3: third smallest value over all lists; u3: the smallest value a list holds without its
-    // index (the third of a list, the fourth when the search kept three indices), i.e. the best
-    // candidate whose INDEX no record holds
-    const float* __restrict__ unnamed = mode2 ? pb.d4 : pb.d3;
-    float u3 = unnamed[row];
     for (int s = 1; s < ns; ++s) {
       const int64_t slot = part_slot(s, row, N, split_row0);
       const ic_top2_rec o = pb.rec[slot];
       const float o3 = pb.d3[slot];
-      u3 = __builtin_fminf(u3, unnamed[slot]);
-      v3 = third_of_union(b.d1, b.d2, v3, o.d1, o.d2, o3);
-      top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
+      hd.u3 = __builtin_fminf(hd.u3, unnamed[slot]);
+      hd.v3 = third_of_union(hd.b.d1, hd.b.d2, hd.v3, o.d1, o.d2, o3);
+      top2_merge_pairs(hd.b.d1, hd.b.i1, hd.b.d2, hd.b.i2, o.d1, o.i1, o.d2, o.i2);
     }
+    return hd;
+  };
+
+  // one row, by the 16 lanes of a group; a row that needs the direct search is put on the list
+  auto full_look = [&](int64_t row, const Head& hd) {
+    const float* xrow = X + row * (int64_t)(WIDE ? D : kD) + sub * 8;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xrow);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xrow + 4);
+    const ic_top2_rec b = hd.b;
+    const float v3 = hd.v3, u3 = hd.u3;
+    const int ns = n_lists(row);
     float xn = group16_sum(chain8(x0, x1, m0, m1));
     if constexpr (WIDE) {
       for (int sl = kD; sl < D; sl += kD)
@@ -1269,9 +1280,11 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
         return tot;
       }
     };
-    float s1 = __builtin_inff(), s2 = __builtin_inff();
-    if (b.i1 >= 0) s1 = direct(b.i1);
-    if (b.i2 >= 0) s2 = direct(b.i2);
+    // both candidates' loads go out together with the row's (an absent candidate reads
+    // codeword 0 and is discarded)
+    float s1 = direct(b.i1 >= 0 ? b.i1 : 0), s2 = direct(b.i2 >= 0 ? b.i2 : 0);
+    if (b.i1 < 0) s1 = __builtin_inff();
+    if (b.i2 < 0) s2 = __builtin_inff();
     // Can a candidate outside the pair be the nearest (the second nearest, when both count)?
     // Only one whose computed value lies within `band` of the reference value: two error bounds,
     // plus what the direct evaluation needs to tell it from the reference candidate(s) -- whose
@@ -1316,7 +1329,17 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   };
 
   if (rowband == nullptr) {
-    for (int64_t row = row_begin + grp; row < row_end; row += 16) full_look(row);
+    // the lists of 256 rows are merged by one thread each (coalesced record reads, one round
+    // trip for all of them), then the groups evaluate the rows: a row's chain of dependent loads
+    // is one step (row + codewords) instead of two (record, then codewords)
+    __shared__ Head heads[256];
+    for (int64_t base = row_begin; base < row_end; base += 256) {   // uniform trip count
+      if (base + threadIdx.x < row_end) heads[threadIdx.x] = merge_lists(base + threadIdx.x);
+      __syncthreads();
+      const int here = row_end - base < 256 ? (int)(row_end - base) : 256;
+      for (int r = grp; r < here; r += 16) full_look(base + r, heads[r]);
+      __syncthreads();
+    }
   } else {
     for (int64_t base = row_begin; base < row_end; base += 256) {   // uniform trip count
       if (threadIdx.x == 0) ntodo = 0;
@@ -1340,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       }
       __syncthreads();
       const int nt = ntodo;
-      for (int t = grp; t < nt; t += 16) full_look(base + todo[t]);
+      for (int t = grp; t < nt; t += 16) full_look(base + todo[t], merge_lists(base + todo[t]));
       __syncthreads();
     }
   }

@@ -38,27 +38,31 @@ __global__ __launch_bounds__(64) void k_count_matches(const uint8_t* __restrict_
   if (threadIdx.x == 0) counts[c] = cnt;
 }
 
-// out[0] = 0, out[i + 1] = counts[0] + ... + counts[i]: one workgroup; every thread sums a
-// contiguous segment, the 256 segment totals are scanned in LDS, then every thread writes the
-// running sums of its segment.
-__global__ __launch_bounds__(256) void k_scan_counts(const int64_t* __restrict__ counts, int64_t n,
-                                                     int64_t* __restrict__ out) {
-  __shared__ int64_t buf[256];
-  const int64_t seg = (n + 255) / 256;
-  const int64_t lo = (int64_t)threadIdx.x * seg;
+// out[0] = 0, out[i + 1] = counts[0] + ... + counts[i]: one workgroup of 1024 threads; every
+// thread sums a contiguous segment (its loads are independent, so they are all in flight at
+// once), the segment totals are scanned by wave shuffles and a 16-entry LDS table, then every
+// thread writes the running sums of its segment.
+__global__ __launch_bounds__(1024) void k_scan_counts(const int64_t* __restrict__ counts,
+                                                      int64_t n, int64_t* __restrict__ out) {
+  __shared__ int64_t wave_total[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t seg = (n + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * seg;
   const int64_t hi = lo + seg < n ? lo + seg : n;
   int64_t total = 0;
+#pragma unroll 8
   for (int64_t i = lo; i < hi; ++i) total += counts[i];
-  buf[threadIdx.x] = total;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int64_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-    __syncthreads();
-    buf[threadIdx.x] += t;
-    __syncthreads();
+  int64_t incl = total;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
   }
-  int64_t run = buf[threadIdx.x] - total;   // exclusive prefix of this segment
-  if (threadIdx.x == 0) out[0] = 0;
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+  int64_t run = incl - total;                 // exclusive prefix inside the wave
+  for (int w = 0; w < wave; ++w) run += wave_total[w];
+  if (tid == 0) out[0] = 0;
   for (int64_t i = lo; i < hi; ++i) {
     run += counts[i];
     out[i + 1] = run;
@@ -759,7 +763,7 @@ hipError_t launch_compact_matches(const uint8_t* mask, const int32_t* i1, const 
                                   int32_t* match_q, int32_t* match_im, double* pts, hipStream_t s) {
   hipLaunchKernelGGL(k_count_matches, dim3((unsigned)n_cand), dim3(64), 0, s, mask, row_off,
                      counts_ws);
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, s, counts_ws, n_cand, out_off);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, counts_ws, n_cand, out_off);
   hipLaunchKernelGGL(k_compact_matches, dim3((unsigned)n_cand), dim3(64), 0, s, mask, i1, row_off,
                      out_off, kp_q, n_q, kp_rows, match_q, match_im, pts);
   return hipGetLastError();
