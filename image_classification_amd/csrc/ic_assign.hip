@@ -1382,7 +1382,9 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
                           const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s) {
-  const int64_t chunk = rescore_chunk(n);
+  // the shortcut path looks at one row per thread: whole blocks of 256 rows per workgroup
+  int64_t chunk = rescore_chunk(n);
+  if (rowband && chunk < 256) chunk = 256;
   const int64_t grid = (n + chunk - 1) / chunk;
   if (grid < 1 || n >= 0x7fffffffLL) return hipErrorInvalidValue;
   // the shortcut answers with an index only
