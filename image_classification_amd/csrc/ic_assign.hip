@@ -256,7 +256,9 @@ __device__ __forceinline__ float key_of(float v, int r) {
 __device__ __forceinline__ void insert3(float& k1, float& k2, float& k3, float x) {
   k3 = __builtin_amdgcn_fmed3f(k2, k3, x);
   k2 = __builtin_amdgcn_fmed3f(k1, k2, x);
-  k1 = __builtin_fminf(k1, x);
+  // the plain instruction: fminf costs three (the compiler first quiets a signalling NaN in
+  // either operand, also when the minimum is written as a median with -inf)
+  asm("v_min_f32 %0, %1, %2" : "=v"(k1) : "v"(k1), "v"(x));
 }
 __device__ __forceinline__ void insert4(float& k1, float& k2, float& k3, float& k4, float x) {
   k4 = __builtin_amdgcn_fmed3f(k3, k4, x);
