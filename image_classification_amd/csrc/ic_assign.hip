@@ -556,7 +556,9 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
   // nothing issued after the stage loads has to be waited for before the first MFMA.
   // It goes global -> LDS directly (lanes 0..31 carry its 512 bytes), through no register.
   float* mu_lds = reinterpret_cast<float*>(smem + 2 * Stage<SK>::kBytes) + wave * kD;
-  if (lane < 32) glds16(aux + lane * 4, reinterpret_cast<char*>(mu_lds));
+  // (the doubled mean, stored behind the padded norms)
+  const float* __restrict__ mean2 = cnp + (K + kStageK - 1) / kStageK * kStageK;
+  if (lane < 32) glds16(mean2 + lane * 4, reinterpret_cast<char*>(mu_lds));
 
   int sti = st;            // codebook stage of the next unit to issue
   int to_issue = left;     // units whose stage has not been issued yet
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     sti = sti + 1 == stages_total ? 0 : sti + 1;
     --to_issue;
   };
-  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max];
+  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max], mean_norm = aux[kAuxMeanNorm];
   int buf = 0;
   bool first = true;
   for (;;) {
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (first) IC_TRACE_NOW(4);
-    // centre the rows on the codebook mean and scale by -2 (exact); on the way, this lane's half
-    // of |x - m|^2 and of (x - m).m for the band
+    // centre the rows on the codebook mean and scale by -2: fma(-2, x, 2 m) rounds once, exactly
+    // like x - m, and doubling is exact; on the way this lane's half of |2 (x - m)|^2
     float xr[1][64];
     float c0[1];
     {
@@ -607,26 +609,28 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
       int moff = h * 16;
       asm volatile("" : "+v"(moff));
       const f32x4* mp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(mu_lds) + moff);
-      float xn = 0.f, xm = 0.f;
+      float xn4 = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const f32x4 mu = mp[2 * q];
+        const f32x4 mu2 = mp[2 * q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float t = xv[q][e] - mu[e];
-          xn = __builtin_fmaf(t, t, xn);
-          xm = __builtin_fmaf(t, mu[e], xm);
-          xr[0][q * 4 + e] = -2.0f * t;
+          const float t = __builtin_fmaf(-2.0f, xv[q][e], mu2[e]);
+          xn4 = __builtin_fmaf(t, t, xn4);
+          xr[0][q * 4 + e] = t;
         }
-        // one chunk after the other: scheduled freely, the sixteen chunks' differences, products
-        // and mean values are all alive at once and a few registers spill to scratch memory
-        // (40 MB of HBM traffic per launch at 1 M rows)
+        // one chunk after the other: scheduled freely, the sixteen chunks' values are all alive
+        // at once and a few registers spill to scratch memory
         __builtin_amdgcn_sched_barrier(0);
       }
-      xn += __shfl_xor(xn, 32);
-      xm += __shfl_xor(xm, 32);
+      xn4 += __shfl_xor(xn4, 32);
+      const float xn = 0.25f * xn4;
+      // the band's constant part needs R = |x - m|^2 + 2 (x - m).m (what separates the computed
+      // value from the squared distance); (x - m).m <= |x - m| |m| spares the second sum per
+      // component, and a larger band only ranks a little more
       const float bound = error_bound(xn, cn_max, cr2_max);
-      c0[0] = 2.01f * bound + kBandSlope * (xn + 2.f * xm);
+      const float r_up = xn + 2.000001f * __builtin_amdgcn_sqrtf(xn) * 1.000001f * mean_norm;
+      c0[0] = 2.01f * bound + kBandSlope * r_up;
     }
     Top2 best[1];
     float gate[1];
@@ -1747,9 +1751,18 @@ __global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, 
     for (int g = 0; g < n_slabs; ++g) t += (double)psum[(int64_t)g * D + col];
     const float m = (float)(t / (double)K);
     mean[col] = m;
-    if (blockIdx.x == 0) aux[mean_off + col] = m;
+    if (blockIdx.x == 0) {
+      aux[mean_off + col] = m;
+      if (D == kD) aux[aux_tail_offset(kpad) + col] = 2.f * m;
+    }
   }
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // |m|, never below the true norm of the stored vector
+    double t = 0.0;
+    for (int col = 0; col < D; ++col) t += (double)mean[col] * (double)mean[col];
+    aux[kAuxMeanNorm] = (float)__builtin_sqrt(t) * (1.f + 2.f * kU);
+  }
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   float cmax = 0.f, rmax = 0.f;

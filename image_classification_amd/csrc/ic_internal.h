@@ -36,15 +36,19 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n);
 // once per device, with that device current: function attributes of the search kernels
 hipError_t assign_init();
 
-// The codebook's auxiliary block, float [kAuxNorms + kpad] (kpad = k rounded up to kStageK) for
-// rows of up to 128 columns, [kAuxNorms + kpad + D] for wider rows (D = columns rounded up to a
-// multiple of 128), whose mean vector does not fit in front and lies behind the norms:
+// The codebook's auxiliary block, float [kAuxNorms + kpad + D] (kpad = k rounded up to kStageK, D
+// = columns rounded up to a multiple of 128):
 constexpr int kAuxCnMax = 128;    // [0, 128) mean vector m (D = 128); [128] max_j |c_j - m|^2
 constexpr int kAuxCr2Max = 129;   // [129] max_j |c_j|^2
+constexpr int kAuxMeanNorm = 130; // [130] |m|, rounded up
 constexpr int kAuxNorms = 256;    // [256 + j] = |c_j - m|^2 for j < k, 3.2e38 for k <= j < kpad
 constexpr int kMaxWideD = 2048;   // widest (padded) row the search handles
-inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? kAuxNorms + kpad : 0; }
-inline int64_t aux_floats(int64_t kpad, int D) { return kAuxNorms + kpad + (D > kD ? D : 0); }
+// behind the norms, D floats: for D = 128 the DOUBLED mean 2 m (what the search kernel centres
+// with: -2 (x - m) = fma(-2, x, 2 m) in one instruction), for wider rows the mean itself, which
+// does not fit in front
+__host__ __device__ inline int64_t aux_tail_offset(int64_t kpad) { return kAuxNorms + kpad; }
+inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? aux_tail_offset(kpad) : 0; }
+inline int64_t aux_floats(int64_t kpad, int D) { return kAuxNorms + kpad + D; }
 // the flagged rows' second look runs on a fixed grid; cut into pieces it holds at most one
 // partial record per (row, piece) with groups x pieces <= the grid, i.e. 16 * kExactGrid records
 constexpr int kExactGrid = 1024;   // (a launch of 4096 workgroups that find nothing to do costs 3 us more)

@@ -171,18 +171,22 @@ def test_top1_matches_top2_and_codebook_aux():
     aux = ops.codebook_aux(cd)
     idx2, dist2 = ops.assign_top1(xd, cd, aux)
     assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
-    # its contents: mean vector, the two maxima, centred squared norms, the padding to 128
-    # (a huge finite norm: padding must never be ranked)
+    # its contents: mean vector, the two maxima, the mean's norm (rounded up), centred squared
+    # norms, the padding to 128 (a huge finite norm: padding must never be ranked), and behind
+    # them the doubled mean the search kernel centres with
     a = aux.cpu().numpy()
     c64 = c.astype(np.float64)
     mean = c64.mean(0)
-    assert a.shape[0] == 256 + 384
+    assert a.shape[0] == 256 + 384 + 128
     assert oracle.check_close(a[:128], mean, rel=1e-6) <= 1e-6
     cn = ((c64 - a[:128].astype(np.float64)) ** 2).sum(1)
     assert oracle.check_close(a[256:256 + 300], cn, rel=1e-5) <= 1e-5
-    assert (a[256 + 300:] > 3.1e38).all() and np.isfinite(a[256 + 300:]).all()
+    assert (a[256 + 300:256 + 384] > 3.1e38).all() and np.isfinite(a[256 + 300:256 + 384]).all()
     assert abs(a[128] - cn.max()) <= 1e-5 * cn.max()
     assert abs(a[129] - (c64 ** 2).sum(1).max()) <= 1e-5 * (c64 ** 2).sum(1).max()
+    m_norm = np.sqrt((a[:128].astype(np.float64) ** 2).sum())
+    assert m_norm <= a[130] <= m_norm * (1 + 1e-6)
+    assert np.array_equal(a[256 + 384:], 2.0 * a[:128])
     # a narrow codebook is padded before its block is taken
     c36 = _dev(c[:, :36])
     i36, d36 = ops.assign_top1(_dev(x[:, :36]), c36, ops.codebook_aux(c36))
