@@ -392,17 +392,33 @@ __device__ __forceinline__ void resolve_tiles(Top2& st, float k1, float k2, floa
 // dense: the tile is one of the first of its scan, where nearly every register holds a candidate
 // some lane must rank: all sixteen are inserted without asking (straight-line code: sixteen
 // compare-and-branch pairs cost more than the inserts they would skip).
-template <bool MODE2>
+// SHORT: the geometry of short scans, where most tiles are dense ones; there the dense tiles
+// skip the tile-minimum test too (in the long-scan geometry that changed nothing but the code
+// layout, for the worse).
+template <bool MODE2, bool SHORT>
 __device__ __forceinline__ void tile_epilogue_gated1(const f32x16& a, Top2& st, float& gate,
                                                      float c0, int tile, float one_plus_slope,
                                                      bool dense = false) {
+  if (SHORT && dense) {
+    // no test at all: the tile minimum would pass in some lane anyway
+    float k1 = st.d1, k2 = st.d2, k3 = st.d3, k4 = st.d4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = key_of(a[r], r);
+      if constexpr (MODE2) insert4(k1, k2, k3, k4, x);
+      else insert3(k1, k2, k3, x);
+    }
+    resolve_tiles<MODE2>(st, k1, k2, k3, k4, tile);
+    gate = __builtin_fmaf(MODE2 ? k2 : k1, one_plus_slope, c0);
+    return;
+  }
   const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
                         min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
                         __builtin_inff());
   if (__builtin_amdgcn_ballot_w64(m < gate) != 0) {
     float k1 = st.d1, k2 = st.d2, k3 = st.d3, k4 = st.d4;
     const float g = gate;
-    if (dense) {
+    if (!SHORT && dense) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float x = key_of(a[r], r);
@@ -424,13 +440,14 @@ __device__ __forceinline__ void tile_epilogue_gated1(const f32x16& a, Top2& st, 
   }
 }
 
-template <int XT, bool MODE2>
+template <int XT, bool MODE2, bool SHORT>
 __device__ __forceinline__ void tile_epilogue_gated(const f32x16 (&acc)[XT], Top2 (&st)[XT],
                                                     float (&gate)[XT], const float (&c0)[XT],
                                                     int tile, bool dense) {
 #pragma unroll
   for (int xt = 0; xt < XT; ++xt)
-    tile_epilogue_gated1<MODE2>(acc[xt], st[xt], gate[xt], c0[xt], tile, 1.f + kBandSlope, dense);
+    tile_epilogue_gated1<MODE2, SHORT>(acc[xt], st[xt], gate[xt], c0[xt], tile, 1.f + kBandSlope,
+                                       dense);
 }
 
 // Every candidate ranked (IC_AMD_VARIANT=0: the timing baseline of the gate).
@@ -684,7 +701,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
           const int tile_no = st * Stage<SK>::kTiles + t;
           // the first kDenseTiles tiles of a scan are ranked without per-register tests
           const bool dense = i * Stage<SK>::kTiles + t < kDenseTiles;
-          if constexpr (GATED) tile_epilogue_gated<1, MODE2>(acc, best, gate, c0, tile_no, dense);
+          if constexpr (GATED) tile_epilogue_gated<1, MODE2, SK == 64>(acc, best, gate, c0, tile_no, dense);
           else tile_epilogue_all<1>(acc, best, tile_no);
         }
       }
@@ -966,7 +983,7 @@ __global__ __launch_bounds__(512, 4) void k_top2_wide(
       for (int t = 0; t < 2; ++t) {
         if ((st * 2 + t) * kTileK < K) {
           if constexpr (GATED)
-            tile_epilogue_gated1<MODE2>(t == 0 ? acc0 : acc1, best[0], gate[0], c0[0], st * 2 + t,
+            tile_epilogue_gated1<MODE2, true>(t == 0 ? acc0 : acc1, best[0], gate[0], c0[0], st * 2 + t,
                                         1.f + band_slope);
           else
             tile_epilogue_all1(t == 0 ? acc0 : acc1, best[0], st * 2 + t);
