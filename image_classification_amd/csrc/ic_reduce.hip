@@ -1,6 +1,7 @@
 // HBM-bound reductions that follow the assignment: per-image bag-of-words histograms and k-means
-// centroid sums.  Both are deterministic and use no atomic instruction at all: every memory word
-// has exactly one writer between two barriers.
+// centroid sums.  Both are deterministic: the histogram counts with integer adds in LDS (exact in
+// any order), the centroid sums add floating-point values in a fixed order with one writer per
+// word between two barriers.
 //
 // What they replace in the reference (paths relative to the reference tree):
 //   np.histogram(code, bins=range(0, K+1))[0] + L1 normalisation   model/features.py:1174-1181
@@ -10,20 +11,14 @@
 namespace ic {
 
 // ---------------------------------------------------------------------------------------------
-// Histogram.  One workgroup of four waves per (image, bin range).  Wave w counts the codes whose
-// two low bits are w, so the waves write disjoint bins and need no barrier between them.  A wave
-// takes 64 codes at a time; lanes holding the same code must not add to its bin in the same
-// instruction, so the lanes first elect one owner per code: every pending lane writes its lane
-// number into a tag slot chosen by the code, reads the slot back, and the lane that finds its own
-// number adds 1 to the bin and retires.  Lanes that lost (same code, or another code on the same
-// slot) go round again; after two rounds the rest is retired one distinct code at a time (ballot
-// of the lanes that hold the first pending lane's code), which bounds the work for images whose
-// descriptors all map to a few words.  LDS operations of one wave execute in order, owners of one round hold
-// different codes, and so every bin has exactly one writer per instruction: no atomics, and the
-// counts do not depend on which lane wins.
+// Histogram.  One workgroup of four waves per (image, bin range): the bins live in LDS, every
+// thread adds 1 to the bin of each of its codes (ds_add_u32; lanes of one instruction that hold
+// the same code are serialised by the hardware, so an image whose descriptors all map to one
+// word costs 64 adds per instruction and nothing worse), then the row is normalised and written.
+// (An earlier version elected one owner lane per code through tag slots instead of using the
+// atomic add: four times the code reads and up to three LDS round trips per 64 codes.)
 constexpr int kHistThreads = 256;
-constexpr int kTagSlots = 1024;      // tag slots per wave
-constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB + 4 KiB of tags in LDS
+constexpr int kHistMaxBins = 32768;  // bins per workgroup: 128 KiB of LDS
 
 __device__ __forceinline__ double block_sum(double v, double* red /*[kHistThreads/64]*/) {
 #pragma unroll
@@ -68,57 +63,33 @@ __global__ __launch_bounds__(kHistThreads) void k_hist(const int32_t* __restrict
   if (nb64 > bins_per_wg) nb64 = bins_per_wg;
   const unsigned nb = (unsigned)nb64;
   volatile unsigned* hist = hsm;
-  const int wave = tid >> 6, lane = tid & 63;
-  // a tag is a lane number: one byte each keeps the workgroup's LDS small (three workgroups of a
-  // 10 000-bin row per CU instead of two)
-  volatile unsigned char* tags = reinterpret_cast<volatile unsigned char*>(hsm + bins_per_wg) + wave * kTagSlots;
-
   for (unsigned b = tid; b < nb; b += kHistThreads) hist[b] = 0;
   const int64_t beg = offsets[img], end = offsets[img + 1];
   __syncthreads();
 
-  // four 64-code pieces per step; the next step's codes are fetched before this step's are counted
+  // every thread counts its own codes with an integer add in LDS (exact in any order); four
+  // codes per thread are in flight, the next four are fetched before these are counted
   constexpr int kU = 4;
   int32_t nxt[kU];
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
-    const int64_t i = beg + u * 64 + lane;
+    const int64_t i = beg + u * kHistThreads + tid;
     nxt[u] = i < end ? codes[i] : -1;
   }
-  for (int64_t base = beg; base < end; base += kU * 64) {
+  for (int64_t base = beg; base < end; base += kU * kHistThreads) {
     int32_t cur[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       cur[u] = nxt[u];
-      const int64_t i = base + (kU + u) * 64 + lane;
+      const int64_t i = base + (kU + u) * kHistThreads + tid;
       nxt[u] = i < end ? codes[i] : -1;
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int64_t c = (int64_t)cur[u] - bin0;
-      bool pending = cur[u] >= 0 && c >= 0 && c < (int64_t)nb && (int)(c & 3) == wave;
-      const unsigned code = (unsigned)c;
-      const unsigned slot = (code >> 2) & (kTagSlots - 1);
-      int rounds = 0;
-      unsigned long long left;
-      while ((left = __builtin_amdgcn_ballot_w64(pending)) != 0) {
-        if (rounds < 2) {
-          ++rounds;
-          if (pending) tags[slot] = (unsigned char)lane;
-          if (pending && tags[slot] == (unsigned char)lane) {
-            hist[code] = hist[code] + 1u;
-            pending = false;
-          }
-        } else {
-          // many lanes hold the same code (a blank frame maps every descriptor to one word):
-          // retire all lanes of the first pending lane's code at once
-          const int first = __builtin_amdgcn_readfirstlane(__builtin_ctzll(left));
-          const unsigned c0 = (unsigned)__builtin_amdgcn_readlane((int)code, first);
-          const unsigned long long same = __builtin_amdgcn_ballot_w64(pending && code == c0);
-          if (lane == first) hist[c0] = hist[c0] + (unsigned)__builtin_popcountll(same);
-          pending = pending && code != c0;
-        }
-      }
+      if (cur[u] >= 0 && c >= 0 && c < (int64_t)nb)
+        __hip_atomic_fetch_add(&hsm[(unsigned)c], 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   __syncthreads();
@@ -205,7 +176,7 @@ __global__ __launch_bounds__(kHistThreads) void k_hist_normalise(int64_t k, int 
 hipError_t reduce_init() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist),
                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                             kHistMaxBins * 4 + (kHistThreads / 64) * kTagSlots);
+                             kHistMaxBins * 4);
 }
 
 hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_img, int64_t k,
@@ -215,7 +186,7 @@ hipError_t launch_hist(const int32_t* codes, const int64_t* offsets, int64_t n_i
   const int bins_per_wg = k < kHistMaxBins ? (int)k : kHistMaxBins;
   const int64_t n_ranges = (k + bins_per_wg - 1) / bins_per_wg;
   if (n_img > 0x7fffffffLL || n_ranges > 65535) return hipErrorInvalidValue;
-  const int lds = bins_per_wg * 4 + (kHistThreads / 64) * kTagSlots;   // see reduce_init()
+  const int lds = bins_per_wg * 4;   // see reduce_init()
   const int fused = n_ranges == 1 ? 1 : 0;
   hipLaunchKernelGGL(k_hist, dim3((unsigned)n_img, (unsigned)n_ranges), dim3(kHistThreads), lds, s,
                      codes, offsets, k, bins_per_wg, norm_mode, power, fused, cell_w, cell_k, out);
