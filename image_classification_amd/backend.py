@@ -49,6 +49,21 @@ class HipBackend(object):
             return self.assign_top1(self.f32(x_np), cb, want_dist)
         return ops.assign_from_host(x_np, cb.c, cb.aux, top2=False, want_dist=want_dist)
 
+    def assign_top1_host(self, x_np, cb):
+        """(idx int32, dist float32) as numpy arrays.  Small inputs come back in ONE download:
+        indices and distances are written into the two halves of one device buffer (a per-image
+        call is dominated by such fixed costs, not by the search)."""
+        x_np = _as_f32_rows(x_np)
+        n = x_np.shape[0]
+        if n > ops.HOST_CHUNK_ROWS:
+            idx, dist = ops.assign_from_host(x_np, cb.c, cb.aux, top2=False, want_dist=True)
+            return idx.cpu().numpy(), dist.cpu().numpy()
+        both = torch.empty(2 * n, dtype=torch.int32, device=self.device)
+        ops.assign_top1(self.f32(x_np), cb.c, cb.aux, True,
+                        out=(both[:n], both[n:].view(torch.float32)))
+        host = both.cpu().numpy()
+        return host[:n], host[n:].view(np.float32)
+
     def assign_top2_np(self, x_np, cb, ratio=0.8):
         x_np = _as_f32_rows(x_np)
         if x_np.shape[0] <= ops.HOST_CHUNK_ROWS:

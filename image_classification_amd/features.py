@@ -134,6 +134,40 @@ class BagOfWords(object):
     def _b(self):
         return getattr(self, "_backend", None) or default_backend()
 
+    # The vocabulary is held as a private read-only copy: nothing outside can edit it in place,
+    # so its device copy is made once and reused without hashing ten megabytes per call (a
+    # per-image `extract` otherwise spends half its time proving that the array is unchanged).
+    # Assigning `bow.vocab = other` replaces it; `bow.vocab[...] = x` raises.
+    @property
+    def vocab(self):
+        held = getattr(self, "_vocab", None)
+        return None if held is None else held.view()
+
+    @vocab.setter
+    def vocab(self, value):
+        self._vocab_cb = None
+        if value is None:
+            self._vocab = None
+            return
+        held = np.array(value, copy=True)
+        held.setflags(write=False)
+        self._vocab = held
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_vocab_cb"] = None        # device memory does not travel
+        return state
+
+    def _codebook(self):
+        """The backend's resident form of the vocabulary, made once per (process, backend)."""
+        b = self._b()
+        key = (os.getpid(), id(b))
+        got = getattr(self, "_vocab_cb", None)
+        if got is None or got[0] != key:
+            got = (key, b.codebook(self._vocab))
+            self._vocab_cb = got
+        return got[1]
+
     # -- descriptors -----------------------------------------------------------------------------
     def _describe(self, image_list, fit_projection=False):
         """Extractor output as ImageDescs, projected when a projection is configured (fitted on
@@ -181,7 +215,7 @@ class BagOfWords(object):
         if not parts:
             return b.i32(np.empty(0, dtype=np.int32)), offsets
         # no host-side concatenation: the per-image arrays are gathered into the upload buffer
-        codes, _ = b.assign_top1_parts(parts, b.codebook(self.vocab), want_dist=False)
+        codes, _ = b.assign_top1_parts(parts, self._codebook(), want_dist=False)
         return codes, offsets
 
     def _quantize(self, image_descs):
@@ -190,7 +224,7 @@ class BagOfWords(object):
             if hasattr(b, "quantize_parts"):
                 # search, histograms and their way back to the host as one pipeline
                 parts, offsets = self._parts_and_offsets(image_descs)
-                _codes, hists = b.quantize_parts(parts, offsets, b.codebook(self.vocab),
+                _codes, hists = b.quantize_parts(parts, offsets, self._codebook(),
                                                  len(self.vocab), self.norm, self.power)
                 return image_descs, hists
             codes, offsets = self._assign_all(image_descs)

@@ -67,11 +67,14 @@ def vq(obs, code_book, check_finite=True, backend=None):
         ct = np.dtype(np.float64)
     if obs_a.shape[0] == 0:
         return np.empty(0, dtype=np.int32), np.empty(0, dtype=ct)
-    idx, dist = b.assign_top1_np(obs_a, cbk, want_dist=True)
-    dist = dist.cpu().numpy()
+    if hasattr(b, "assign_top1_host"):
+        idx, dist = b.assign_top1_host(obs_a, cbk)
+    else:
+        idx, dist = b.assign_top1_np(obs_a, cbk, want_dist=True)
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     if check_finite and big and not np.isfinite(dist).all():
         raise ValueError("array must not contain infs or NaNs")
-    return idx.cpu().numpy(), dist.astype(ct)
+    return idx, dist.astype(ct)
 
 
 def kmeans2(data, k, iter=10, thresh=1e-5, minit="points", missing="warn", check_finite=True,

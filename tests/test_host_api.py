@@ -710,3 +710,31 @@ def test_bag_of_words_model_directory_round_trip(backend, tmp_path):
     sback = SpatialBagOfWords.load_from_dir(str(tmp_path / "sbow"), backend=backend)
     assert (sback.n_levels, sback.im_height, sback.im_width) == (2, 40, 60)
     assert isinstance(sback, SpatialBagOfWords)
+
+
+def test_bag_of_words_keeps_a_private_read_only_vocabulary(backend):
+    # the vocabulary is copied and frozen when it is set, so its device copy needs no re-hashing
+    # per call; editing the caller's array afterwards changes nothing, assigning a new one does
+    rng = np.random.default_rng(3)
+    vocab = rng.random((40, 16))
+    feats = rng.random((300, 16)).astype(np.float32)
+
+    class _Ext(object):
+        def extract(self, image_list):
+            return [([(0.0, 0.0)] * 100, feats[i * 100:(i + 1) * 100]) for i in image_list]
+
+    bow = BagOfWords(_Ext(), vocab=vocab, backend=backend)
+    _, h0 = bow.extract([0, 1, 2])
+    mine = vocab.copy()
+    vocab[:] = 0.0                                   # the caller's array is not the model's
+    _, h1 = bow.extract([0, 1, 2])
+    assert np.array_equal(h0, h1) and np.array_equal(bow.vocab, mine)
+    with pytest.raises(ValueError):
+        bow.vocab[0, 0] = 1.0
+    with pytest.raises(ValueError):
+        bow.vocab.setflags(write=True)
+    bow.vocab = mine[::-1]                           # a new vocabulary: words renumbered
+    _, h2 = bow.extract([0, 1, 2])
+    assert np.array_equal(h2, h0[:, ::-1])
+    # the device copy is per process and does not travel with a pickled model
+    assert bow._vocab_cb is not None and bow.__getstate__()["_vocab_cb"] is None
