@@ -117,6 +117,7 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide) {
   p->full_tiles = forced > 0 ? 0 : p->row_tiles / slots * slots;
   const int64_t tail = p->row_tiles - p->full_tiles;
   p->tail_quota = (int)stages;
+  p->tail_span = (int)stages;
   p->tail_wgs = tail;
   p->max_pieces = 1;
   if (tail == 0) return;
@@ -132,6 +133,24 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide) {
   p->tail_wgs = (units + q - 1) / q;
   const int64_t pieces = (stages - 1) / q + 2;     // runs a row tile's stages can fall into
   p->max_pieces = (int)(pieces < stages ? pieces : stages);
+  // Few row tiles against a long codebook (a handful of queries against a 2M-row index): cut
+  // every row tile at the SAME stages instead, P pieces each with P a multiple of 8, so that
+  // the workgroups that scan one range of the codebook for different row tiles are resident
+  // together on one XCD (workgroup ids that differ by a multiple of 8) and its L2 fetches the
+  // range once for all of them; with runs that start anywhere, every row tile's scan fetched the
+  // whole codebook from HBM again.  In the line of units a row tile then takes P q >= stages
+  // places (the last piece of a tile is shorter).  Taken when it costs at most 2 % of balance.
+  if (forced <= 0 && !wide && tail * 8 <= slots) {
+    const int64_t P = slots / tail / 8 * 8;
+    const int64_t qa = (stages + P - 1) / P;
+    const int64_t Pa = (stages + qa - 1) / qa;     // pieces that are not empty
+    if (qa >= 2 && Pa * qa * 100 <= stages * 102 && qa * 100 <= q * 102) {
+      p->tail_quota = (int)qa;
+      p->tail_span = (int)(Pa * qa);
+      p->tail_wgs = tail * Pa;
+      p->max_pieces = (int)Pa;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,7 +510,7 @@ __device__ __forceinline__ int64_t part_slot(int l, int64_t r, int64_t N, int64_
 // units [g q, (g + 1) q).  The pieces of a row tile are the runs its units fall into, numbered
 // from the first such run.
 struct TailGeom {
-  int stages;        // S
+  int stages;        // S: units a row tile takes in the line (AssignPlan::tail_span)
   int quota;         // q
   int rows_per_wg;
 };
@@ -532,9 +551,9 @@ __device__ unsigned long long ic_trace_buf[kTraceWgs][8];
 template <int XT, int NW, int SK, bool GATED, bool MODE2>
 __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
-    const float* __restrict__ aux, int stages_total, int full_tiles, int64_t tail_units,
-    int tail_quota, const float* __restrict__ thr, PartBufs pb, float* __restrict__ rowband,
-    uint32_t* __restrict__ zero_word) {
+    const float* __restrict__ aux, int stages_total, int tail_span, int full_tiles,
+    int64_t tail_units, int tail_quota, const float* __restrict__ thr, PartBufs pb,
+    float* __restrict__ rowband, uint32_t* __restrict__ zero_word) {
   static_assert(XT == 1, "one 32-descriptor tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -558,13 +577,16 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
   int tile = blockIdx.x;
   int st = 0, left = stages_total, piece = 0;
   if ((int)blockIdx.x >= full_tiles) {
+    // (tail_span = stages_total: runs may cross into the next row tile; larger: the runs are
+    // aligned to the row tiles and the places behind a tile's last stage are padding)
     const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
-    const int64_t tt = u / stages_total;
+    const int64_t tt = u / tail_span;
     const int64_t rest = tail_units - u;
     tile = full_tiles + (int)tt;
-    st = (int)(u - tt * stages_total);
+    st = (int)(u - tt * tail_span);
     left = rest < tail_quota ? (int)rest : tail_quota;
-    piece = ((int)blockIdx.x - full_tiles) - (int)(tt * stages_total / tail_quota);
+    if (tail_span != stages_total && left > stages_total - st) left = stages_total - st;
+    piece = ((int)blockIdx.x - full_tiles) - (int)(tt * tail_span / tail_quota);
   }
   const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
   const int n_rows = (int)N;
@@ -770,12 +792,13 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   const int64_t grid = plan.full_tiles + plan.tail_wgs;
   // the kernel's geometry must be the plan's: it indexes rows and records by it
   if (stages != plan.stages || plan.rows_per_wg != NW * 32 || plan.tail_quota < 1 ||
-      plan.tail_wgs != (tail_tiles * stages + plan.tail_quota - 1) / plan.tail_quota)
+      plan.tail_span < stages || (plan.tail_span != stages && plan.tail_span % plan.tail_quota != 0) ||
+      plan.tail_wgs != (tail_tiles * plan.tail_span + plan.tail_quota - 1) / plan.tail_quota)
     return hipErrorInvalidValue;
   if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
-                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota, thr,
-                     pb, rowband, zero_word);
+                     (int)stages, plan.tail_span, (int)plan.full_tiles,
+                     tail_tiles * plan.tail_span, plan.tail_quota, thr, pb, rowband, zero_word);
   return hipGetLastError();
 }
 
@@ -1416,7 +1439,7 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
   auto kern = D > kD ? k_rescore<true> : k_rescore<false>;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb,
-                     rowband, TailGeom{plan.stages, plan.tail_quota, plan.rows_per_wg},
+                     rowband, TailGeom{plan.tail_span, plan.tail_quota, plan.rows_per_wg},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);
   return hipGetLastError();

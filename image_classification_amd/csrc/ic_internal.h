@@ -24,6 +24,8 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 struct AssignPlan {
   int waves, stage_k, rows_per_wg;
   int stages;                      // codebook stages
+  int tail_span;                   // units a tail row tile takes in the line of (row tile, stage)
+                                   // pairs: `stages`, or more when the runs are aligned (padding)
   int64_t row_tiles, full_tiles;
   int tail_quota, max_pieces;
   int64_t tail_wgs;
