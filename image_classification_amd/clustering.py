@@ -11,6 +11,7 @@ returned are those of the last assignment, i.e. from before the last update.
 import warnings
 
 import numpy as np
+import torch
 
 from .backend import default_backend
 
@@ -40,8 +41,16 @@ def lloyd(xd, c0, iters, backend, allreduce=None, on_empty=None, labels0=None):
     labels0: labels from an earlier call with these rows (a guess for the first assignment).
     Returns (codebook device tensor, labels int32 device tensor, empties per iteration).
     """
+    k, d = c0.shape
+    # The search works on rows of a multiple of 128 columns and pads others with zeros on every
+    # call; the rows are the same in every iteration, so they are padded once here.  Zero columns
+    # change no distance, no sum and no mean (the centroids' padding stays zero), and the library
+    # would have searched exactly these padded rows: same labels, same centroids.
+    width = -(-d // 128) * 128
+    if width != d and xd.shape[0] > 0:
+        xd = torch.nn.functional.pad(xd, (0, width - d))
+        c0 = torch.nn.functional.pad(c0, (0, width - d))
     cb = backend.make_codebook(c0)
-    k = c0.shape[0]
     labels = labels0
     empties = []
     for _ in range(int(iters)):
@@ -62,7 +71,8 @@ def lloyd(xd, c0, iters, backend, allreduce=None, on_empty=None, labels0=None):
         if n_empty and on_empty is not None:
             on_empty()
         cb = backend.make_codebook(new_c)
-    return cb.c, labels, empties
+    c = cb.c if width == d else cb.c[:, :d].contiguous()
+    return c, labels, empties
 
 
 def _warn_empty():

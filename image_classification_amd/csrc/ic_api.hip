@@ -128,6 +128,27 @@ int finish_call(Ctx* c, hipStream_t s) {
   return IC_OK;
 }
 
+// A call that fails half way (a launch is refused) may already have enqueued kernels that use the
+// workspace: leaving through an error return, the call is closed like a finished one, so that
+// the next call -- on whatever stream -- is still ordered behind that work.  The error being
+// returned is the one the caller sees; a failure of the record itself is not reported over it.
+struct CallScope {
+  Ctx* c;
+  hipStream_t s;
+  bool open = true;
+  CallScope(Ctx* ctx, hipStream_t stream) : c(ctx), s(stream) {}
+  int finish() {
+    open = false;
+    return finish_call(c, s);
+  }
+  ~CallScope() {
+    if (open && hipEventRecord(c->done, s) == hipSuccess) {
+      c->last_stream = s;
+      c->have_last = true;
+    }
+  }
+};
+
 // When the handle is profiling: records the start event of a dominant-kernel launch on `s` and
 // hands back the stop event to record after it (null otherwise).
 int profile_open(Ctx* c, hipStream_t s, hipEvent_t* stop) {
@@ -192,11 +213,11 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
 
   const int64_t kpad = (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK;
   ic::AssignPlan plan;
-  ic::assign_plan(n, k, ctx->num_cus, &plan, D > ic::kD);
+  ic::assign_plan(n, k, ctx->num_cus, &plan, D);
   const size_t records = (size_t)ic::assign_part_records(plan, n);
   size_t off = 0;
   auto take = [&off](size_t bytes) { const size_t o = off; off += align_up(bytes); return o; };
-  const size_t o_aux = c_aux ? 0 : take((size_t)ic::aux_floats(kpad, D) * 4);
+  const size_t o_aux = c_aux ? 0 : take((size_t)ic::aux_floats(k, kpad, D) * 4);
   const size_t o_auxs = c_aux ? 0 : take(ic::codebook_aux_scratch_bytes(k, D));
   const size_t o_part = take(records * sizeof(ic_top2_rec));
   const size_t o_part3 = take(records * 4);
@@ -231,6 +252,9 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     if (rc) return rc;
     ws = ctx->ws;
   }
+  // (the static entry point uses no handle state: nothing to close)
+  CallScope scope(ctx, s);
+  if (use_static) scope.open = false;
 
   const ic::PartBufs pb{reinterpret_cast<ic_top2_rec*>(ws + o_part),
                         reinterpret_cast<float*>(ws + o_part3),
@@ -253,10 +277,18 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     aux = a;
   }
   const float* mean = aux + ic::aux_mean_offset(kpad, D);
+  // a codebook kept in search order inside its auxiliary block: the matrix-core kernel scans that
+  // copy, everything else works on the caller's codebook and translates through perm / rank
+  const bool ordered = ic::aux_ordered(k, D);
+  const float* c_search = ordered ? aux + ic::aux_cperm_offset(kpad) : cs;
+  const int32_t* perm =
+      ordered ? reinterpret_cast<const int32_t*>(aux + ic::aux_perm_offset(kpad)) : nullptr;
+  const int32_t* rank =
+      ordered ? reinterpret_cast<const int32_t*>(aux + ic::aux_rank_offset(kpad)) : nullptr;
   float* thr = nullptr;
   if (hint) {
     thr = reinterpret_cast<float*>(ws + o_thr);
-    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, aux, mean, D, hint, thr, s),
+    IC_HIP(ic::launch_hint_threshold(xs, n, cs, k, aux, mean, D, hint, rank, thr, s),
            "hint threshold kernel");
   }
   hipEvent_t ev1 = nullptr;
@@ -268,12 +300,12 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   int32_t* list = reinterpret_cast<int32_t*>(ws + o_list);
   uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
   uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + o_tickets);
-  IC_HIP(ic::launch_top2_partial(xs, n, cs, k, aux, mean, D, plan, mode2, thr, pb, rowband,
+  IC_HIP(ic::launch_top2_partial(xs, n, c_search, k, aux, mean, D, plan, mode2, thr, pb, rowband,
                                  wide ? reinterpret_cast<float*>(ws + o_xc) : nullptr, count, s),
          "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   if (!index_only) rowband = nullptr;   // k_rescore's shortcut answers index-only calls
-  IC_HIP(ic::launch_rescore(xs, n, cs, aux, mean, D, pb, rowband, plan, mode2, i1, d1, i2, d2,
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, mean, D, pb, perm, rowband, plan, mode2, i1, d1, i2, d2,
                             ratio, mask, rec, list, count, tickets, s),
          "rescore kernel");
   IC_HIP(ic::launch_exact_rows(xs, n, cs, k, D, list, count,
@@ -284,7 +316,7 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
     IC_HIP(hipMemcpyAsync(ctx->debug_count, count, 4, hipMemcpyDeviceToDevice, s),
            "hipMemcpyAsync");
   }
-  return use_static ? IC_OK : finish_call(ctx, s);
+  return use_static ? IC_OK : scope.finish();
 }
 
 }  // namespace
@@ -427,7 +459,7 @@ int64_t ic_codebook_aux_floats(int64_t k) { return ic_codebook_aux_floats_d(k, i
 int64_t ic_codebook_aux_floats_d(int64_t k, int d) {
   if (k < 1 || d < 1 || d > ic::kMaxWideD) return 0;
   const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
-  return ic::aux_floats((k + ic::kStageK - 1) / ic::kStageK * ic::kStageK, D);
+  return ic::aux_floats(k, (k + ic::kStageK - 1) / ic::kStageK * ic::kStageK, D);
 }
 
 int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, void* stream) {
@@ -450,6 +482,7 @@ int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, 
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
+  CallScope scope(ctx, s);
   const float* cs = c;
   if (pad) {
     float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
@@ -457,7 +490,7 @@ int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, 
     cs = cp;
   }
   IC_HIP(ic::launch_codebook_aux(cs, k, D, aux, ctx->ws, s), "codebook auxiliary block");
-  return finish_call(ctx, s);
+  return scope.finish();
 }
 
 int ic_debug_flagged(void* handle, uint32_t* count) {
@@ -519,12 +552,15 @@ int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c
   if (!guard.ok) return fail_hip(guard.err, "hipSetDevice");
   const float* xs = x;
   const float* cs = c;
+  CallScope scope(ctx, s);
+  scope.open = false;   // only the padded copies live in the workspace
   if (d != D) {
     const size_t o_cp = align_up((size_t)n * D * 4);
     int rc = ensure_ws(ctx, o_cp + align_up((size_t)k * D * 4));
     if (rc) return rc;
     rc = order_after_previous(ctx, s);
     if (rc) return rc;
+    scope.open = true;
     float* xp = reinterpret_cast<float*>(ctx->ws);
     float* cp = reinterpret_cast<float*>(ctx->ws + o_cp);
     IC_HIP(ic::launch_pad_rows(x, n, d, D, xp, s), "pad descriptors");
@@ -534,7 +570,7 @@ int ic_assign_top2_exact(void* handle, const float* x, int64_t n, const float* c
   }
   IC_HIP(ic::launch_exact_top2(xs, n, cs, k, D, i1, d1, i2, d2, ratio, mask, s),
          "direct search kernel");
-  return d != D ? finish_call(ctx, s) : IC_OK;
+  return d != D ? scope.finish() : IC_OK;
 }
 
 int ic_assign_top2_rec(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
@@ -607,11 +643,12 @@ int ic_spatial_hist(void* handle, const int32_t* codes, const int32_t* kp_cells,
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
+  CallScope scope(ctx, s);
   IC_HIP(ic::launch_spatial_hist(codes, kp_cells, n_img, n_kp, n_levels, k, n_cells, cell_weights,
                                  reinterpret_cast<int32_t*>(ctx->ws + o_keys),
                                  reinterpret_cast<int64_t*>(ctx->ws + o_off), out, s),
          "spatial histogram kernels");
-  return finish_call(ctx, s);
+  return scope.finish();
 }
 
 int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int64_t n, int64_t k,
@@ -646,20 +683,22 @@ int ic_centroid_partials(void* handle, const float* x, const int32_t* codes, int
     if (rc) return rc;
     rc = order_after_previous(ctx, s);
     if (rc) return rc;
+    CallScope scope(ctx, s);
     IC_HIP(ic::launch_centroid_partials_scan(x, codes, n, k, d, n_rr,
                                              reinterpret_cast<double*>(ctx->ws + o_ps),
                                              reinterpret_cast<int64_t*>(ctx->ws + o_pc), sums,
                                              counts, s),
            "centroid sums kernel (scan)");
-    return finish_call(ctx, s);
+    return scope.finish();
   }
   int rc = ensure_ws(ctx, plan.bytes);
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
+  CallScope scope(ctx, s);
   IC_HIP(ic::launch_centroid_partials(x, codes, n, k, d, plan, ctx->ws, sums, counts, s),
          "centroid sums kernels");
-  return finish_call(ctx, s);
+  return scope.finish();
 }
 
 int ic_centroid_finalize(void* handle, const double* sums, const int64_t* counts,
@@ -725,6 +764,7 @@ int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
+  CallScope scope(ctx, s);
   double* dist = reinterpret_cast<double*>(ctx->ws);
   double* part_d = reinterpret_cast<double*>(ctx->ws + o_pd);
   int32_t* part_i = reinterpret_cast<int32_t*>(ctx->ws + o_pi);
@@ -740,7 +780,7 @@ int ic_knn_rows(void* handle, const float* x, int64_t m, const float* c, int64_t
                                 out_idx + r0 * k, s),
            "row top-k kernels");
   }
-  return finish_call(ctx, s);
+  return scope.finish();
 }
 
 int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
@@ -768,11 +808,12 @@ int ic_compact_matches(void* handle, const uint8_t* mask, const int32_t* i1,
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
+  CallScope scope(ctx, s);
   IC_HIP(ic::launch_compact_matches(mask, i1, row_offsets, n_cand, kp_query, n_query, kp_rows,
                                     reinterpret_cast<int64_t*>(ctx->ws), out_offsets, match_q,
                                     match_im, pts, s),
          "match compaction kernels");
-  return finish_call(ctx, s);
+  return scope.finish();
 }
 
 int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets, int64_t n_cand,
@@ -797,11 +838,12 @@ int ic_ransac_homography(void* handle, const double* pts, const int64_t* offsets
   if (rc) return rc;
   rc = order_after_previous(ctx, s);
   if (rc) return rc;
+  CallScope scope(ctx, s);
   IC_HIP(ic::launch_ransac(pts, offsets, n_cand, n_iter, samples, seed, th, min_inliers,
                            flags, reinterpret_cast<int32_t*>(ctx->ws), H, n_inliers,
                            best_err, best_iter, inlier_mask, s),
          "homography RANSAC kernels");
-  return finish_call(ctx, s);
+  return scope.finish();
 }
 
 }  // extern "C"

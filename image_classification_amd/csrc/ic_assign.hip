@@ -93,7 +93,12 @@ constexpr int kSmallCodebook = 8192;   // below this: two 8-wave workgroups per 
 // the tail takes run g, which may end one row tile and begin the next.  Every workgroup then has
 // the same amount of matrix work, a row tile is loaded by at most max_pieces workgroups, and the
 // codebook stages keep streaming through LDS across the change of row tile.
-void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide) {
+// Rows of kWidePieceD columns and more are cut differently (see k_top2_wide).
+constexpr int kWidePieceD = 512;
+constexpr int kWidePieces = 16;
+
+void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
+  const bool wide = D > kD;
   // IC_AMD_GEOMETRY forces a shape (1 = two 8-wave workgroups per CU, 2 = one of 16; tuning aid)
   static const int geom = [] {
     const char* v = getenv("IC_AMD_GEOMETRY");
@@ -120,6 +125,29 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide) {
   p->tail_span = (int)stages;
   p->tail_wgs = tail;
   p->max_pieces = 1;
+  p->wide_pieces = 0;
+  if (wide && D >= kWidePieceD && forced <= 0) {
+    // A workgroup of the wide search reads its 256 rows again for every chunk of 64 codewords,
+    // and the rows of all resident workgroups together (0.5 MB x D / 128 ... 1 GB at 2048
+    // columns) fit no cache: walked whole, a row tile's scan is bound by those reads.  So every
+    // row tile is cut into P pieces of q chunks, and the P workgroups of a row tile get
+    // consecutive places on ONE XCD (workgroup id = 8 * place + XCD): they start together, walk
+    // the slabs of the same rows at the same pace, and the XCD's L2 fetches each slab once for
+    // all of them.  P = 16 (every chunk its own piece below 16 chunks), more when the row tiles
+    // are too few to fill the machine otherwise.
+    int64_t want = (slots + p->row_tiles - 1) / p->row_tiles;
+    if (want < kWidePieces) want = kWidePieces;
+    if (want > stages) want = stages;
+    const int64_t q = (stages + want - 1) / want;
+    const int64_t P = (stages + q - 1) / q;
+    p->full_tiles = 0;
+    p->tail_quota = (int)q;
+    p->tail_span = (int)(P * q);
+    p->tail_wgs = p->row_tiles * P;
+    p->max_pieces = (int)P;
+    p->wide_pieces = (int)P;
+    return;
+  }
   if (tail == 0) return;
   // cutting pays when the idle slots of the round are worth more than the extra row-tile loads
   // (about two stages' time per workgroup)
@@ -905,7 +933,7 @@ template <bool GATED, bool MODE2>
 __global__ __launch_bounds__(512, 4) void k_top2_wide(
     const float* __restrict__ XC, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ aux, int D, int stages_total, int full_tiles, int64_t tail_units,
-    int tail_quota, const float* __restrict__ thr, PartBufs pb,
+    int tail_quota, int pieces, const float* __restrict__ thr, PartBufs pb,
     const float* __restrict__ rowc0, uint32_t* __restrict__ zero_word) {
   constexpr int NW = 8, SK = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -920,7 +948,16 @@ __global__ __launch_bounds__(512, 4) void k_top2_wide(
   // the walk over (row tile, chunk of 64 codewords) units, as in k_top2_partial
   int tile = blockIdx.x;
   int st = 0, left = stages_total, piece = 0;
-  if ((int)blockIdx.x >= full_tiles) {
+  if (pieces > 0) {
+    // piece `piece` of row tile `tile`: chunks [piece q, piece q + q); the pieces of a row tile
+    // sit at consecutive places of one XCD (workgroups are dealt to the 8 XCDs in turn)
+    const int xcd = blockIdx.x & 7, place = blockIdx.x >> 3;
+    tile = place / pieces * 8 + xcd;
+    piece = place - place / pieces * pieces;
+    st = piece * tail_quota;
+    left = stages_total - st < tail_quota ? stages_total - st : tail_quota;
+    if ((int64_t)tile * (NW * 32) >= N) return;   // the grid is rounded up to 8 row tiles
+  } else if ((int)blockIdx.x >= full_tiles) {
     const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
     const int64_t tt = u / stages_total;
     const int64_t rest = tail_units - u;
@@ -1044,11 +1081,23 @@ static hipError_t launch_wide(const float* x, int64_t n, const float* c, int64_t
                               float* rowc0, uint32_t* zero_word, hipStream_t s) {
   const int64_t stages = (k + 63) / 64;
   const int64_t tail_tiles = plan.row_tiles - plan.full_tiles;
-  if (plan.waves != 8 || plan.stage_k != 64 || stages != plan.stages || plan.tail_quota < 1 ||
-      plan.tail_wgs != (tail_tiles * stages + plan.tail_quota - 1) / plan.tail_quota ||
+  const int64_t P = plan.wide_pieces, q = plan.tail_quota;
+  if (plan.waves != 8 || plan.stage_k != 64 || stages != plan.stages || q < 1 ||
       D <= kD || D % kD != 0 || D > kMaxWideD || !xc || !rowc0)
     return hipErrorInvalidValue;
-  const int64_t grid = plan.full_tiles + plan.tail_wgs;
+  int64_t grid;
+  if (P > 0) {
+    // the kernel and k_rescore index the records by this geometry: P pieces of q chunks per row
+    // tile, none of them empty
+    if (plan.full_tiles != 0 || plan.tail_span != P * q || plan.max_pieces != P ||
+        P * q < stages || (P - 1) * q >= stages || plan.tail_wgs != plan.row_tiles * P)
+      return hipErrorInvalidValue;
+    grid = (plan.row_tiles + 7) / 8 * 8 * P;
+  } else {
+    if (plan.tail_span != stages || plan.tail_wgs != (tail_tiles * stages + q - 1) / q)
+      return hipErrorInvalidValue;
+    grid = plan.full_tiles + plan.tail_wgs;
+  }
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   int64_t cgrid = (n + 15) / 16;
   if (cgrid > 16384) cgrid = 16384;
@@ -1061,8 +1110,8 @@ static hipError_t launch_wide(const float* x, int64_t n, const float* c, int64_t
                       : k_top2_wide<true, false>;
   const int lds = 2 * Stage<64>::kBytes;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, xc, n, c, (int)k, aux, D,
-                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota, thr,
-                     pb, rowc0, zero_word);
+                     (int)stages, (int)plan.full_tiles, tail_tiles * stages, plan.tail_quota, (int)P,
+                     thr, pb, rowc0, zero_word);
   return hipGetLastError();
 }
 
@@ -1244,6 +1293,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
                                                  const float* __restrict__ aux, int D,
                                                  const float* __restrict__ mean,
                                                  PartBufs pb,
+                                                 const int32_t* __restrict__ perm,
                                                  const float* __restrict__ rowband, TailGeom tail,
                                                  int64_t split_row0, int mode2, int64_t chunk,
                                                  FinalOut out, int32_t* __restrict__ list,
@@ -1276,16 +1326,27 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     ic_top2_rec b;
     float v3, u3;
   };
+  // The lists name codewords by their position in the order the matrix-core kernel scanned them;
+  // with `perm` that is not the codebook's own order, and every index is translated as it is
+  // read, so that all that follows -- merging, direct evaluation, tie-breaking by (distance,
+  // index), outputs -- happens in codeword indices.
+  auto named = [&](int idx) { return (perm && idx >= 0) ? perm[idx] : idx; };
+  auto load_rec = [&](int64_t slot) {
+    ic_top2_rec r = pb.rec[slot];
+    r.i1 = named(r.i1);
+    r.i2 = named(r.i2);
+    return r;
+  };
   const float* __restrict__ unnamed = mode2 ? pb.d4 : pb.d3;
   auto merge_lists = [&](int64_t row) {
     Head hd;
-    hd.b = pb.rec[row];
+    hd.b = load_rec(row);
     hd.v3 = pb.d3[row];
     hd.u3 = unnamed[row];
     const int ns = n_lists(row);
     for (int s = 1; s < ns; ++s) {
       const int64_t slot = part_slot(s, row, N, split_row0);
-      const ic_top2_rec o = pb.rec[slot];
+      const ic_top2_rec o = load_rec(slot);
       const float o3 = pb.d3[slot];
       hd.u3 = __builtin_fminf(hd.u3, unnamed[slot]);
       hd.v3 = third_of_union(hd.b.d1, hd.b.d2, hd.v3, o.d1, o.d2, o3);
@@ -1351,8 +1412,8 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       // evaluated
       for (int s = 0; s < ns; ++s) {
         const int64_t slot = part_slot(s, row, N, split_row0);
-        const ic_top2_rec o = pb.rec[slot];
-        const int cand[3] = {o.i1, o.i2, mode2 ? pb.i3[slot] : -1};
+        const ic_top2_rec o = load_rec(slot);
+        const int cand[3] = {o.i1, o.i2, mode2 ? named(pb.i3[slot]) : -1};
         const float val[3] = {o.d1, o.d2, mode2 ? pb.d3[slot] : 0.f};
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -1392,10 +1453,10 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       __syncthreads();
       const int64_t row = base + threadIdx.x;
       if (row < row_end) {
-        ic_top2_rec b = pb.rec[row];
+        ic_top2_rec b = load_rec(row);
         const int ns = n_lists(row);
         for (int s = 1; s < ns; ++s) {
-          const ic_top2_rec o = pb.rec[part_slot(s, row, N, split_row0)];
+          const ic_top2_rec o = load_rec(part_slot(s, row, N, split_row0));
           top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
         }
         // the gate's band of the best: everything outside the pair lies above b.d2 or was
@@ -1424,10 +1485,11 @@ int64_t rescore_chunk(int64_t n) {
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const float* mean, int D, const PartBufs& pb, const float* rowband,
-                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
-                          float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
-                          uint32_t* count, uint32_t* tickets, hipStream_t s) {
+                          const float* mean, int D, const PartBufs& pb, const int32_t* perm,
+                          const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1,
+                          float* d1, int32_t* i2, float* d2, float ratio, uint8_t* mask,
+                          ic_top2_rec* rec, int32_t* list, uint32_t* count, uint32_t* tickets,
+                          hipStream_t s) {
   // the shortcut path looks at one row per thread: whole blocks of 256 rows per workgroup
   int64_t chunk = rescore_chunk(n);
   if (rowband && chunk < 256) chunk = 256;
@@ -1438,7 +1500,7 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (mode2 && (!pb.i3 || !pb.d4)) return hipErrorInvalidValue;
   if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
   auto kern = D > kD ? k_rescore<true> : k_rescore<false>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb, perm,
                      rowband, TailGeom{plan.tail_span, plan.tail_quota, plan.rows_per_wg},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);
@@ -1458,6 +1520,7 @@ __global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict_
                                                         const float* __restrict__ aux,
                                                         const float* __restrict__ mean, int D,
                                                         const int32_t* __restrict__ hint,
+                                                        const int32_t* __restrict__ rank,
                                                         float* __restrict__ thr) {
   const int sub = threadIdx.x & 15;
   const int64_t stride = (int64_t)gridDim.x * 16;
@@ -1484,7 +1547,8 @@ __global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict_
     xn = group16_sum(xn);
     xm = group16_sum(xm);
     if (sub == 0) {
-      const float v = aux[kAuxNorms + hh] - 2.f * dot;
+      // (the norms follow the search order when the codebook has one)
+      const float v = aux[kAuxNorms + (rank ? rank[hh] : hh)] - 2.f * dot;
       const float bound = error_bound_d(xn, cn_max, cr2_max, D);
       const float sq = __builtin_fmaxf(xn + 2.f * xm + v, 0.f);   // about the squared distance
       thr[row] = ok ? __builtin_fminf(v + 7.f * bound + band_slope * sq + 1e-30f, kNone) : kNone;
@@ -1494,12 +1558,12 @@ __global__ __launch_bounds__(256) void k_hint_threshold(const float* __restrict_
 
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
                                  const float* aux, const float* mean, int D, const int32_t* hint,
-                                 float* thr, hipStream_t s) {
+                                 const int32_t* rank, float* thr, hipStream_t s) {
   int64_t grid = (n + 15) / 16;
   if (grid > 16384) grid = 16384;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_hint_threshold, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, k, aux,
-                     mean, D, hint, thr);
+                     mean, D, hint, rank, thr);
   return hipGetLastError();
 }
 
@@ -1783,6 +1847,7 @@ __global__ __launch_bounds__(256) void k_aux_colsum(const float* __restrict__ C,
 __global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, int64_t K, int D,
                                                    int64_t kpad, const float* __restrict__ psum,
                                                    int n_slabs, float* __restrict__ aux,
+                                                   float* __restrict__ norms_out,
                                                    int64_t mean_off, float* __restrict__ pmax) {
   extern __shared__ __attribute__((aligned(16))) float mean[];   // [D]
   __shared__ float wmax[2][16];
@@ -1824,7 +1889,7 @@ __global__ __launch_bounds__(256) void k_aux_norms(const float* __restrict__ C, 
       cmax = __builtin_fmaxf(cmax, cn);
       rmax = __builtin_fmaxf(rmax, rn);
     }
-    if (sub == 0) aux[kAuxNorms + row] = cn;
+    if (sub == 0) norms_out[row] = cn;
   }
   if (sub == 0) {
     wmax[0][grp] = cmax;
@@ -1856,6 +1921,65 @@ __global__ __launch_bounds__(64) void k_aux_max(const float* __restrict__ pmax, 
   }
 }
 
+// The search order of a codebook: rank of every codeword by (|c_j - m|^2, j), counted -- 64
+// codewords per workgroup, every wave counting over a quarter of each 1024-norm tile -- and the
+// norms, the permutation both ways and the codewords themselves laid out in that order.  The
+// norms are compared as bit patterns: a total order whatever the input holds, so the ranks are
+// a permutation even when norms are NaN, and no position of the ordered copy stays unwritten.
+__global__ __launch_bounds__(256) void k_order_codebook(const float* __restrict__ norm0, int K,
+                                                        int kpad, const float* __restrict__ C,
+                                                        float* __restrict__ norms_out,
+                                                        int32_t* __restrict__ perm,
+                                                        int32_t* __restrict__ rank,
+                                                        float* __restrict__ cperm) {
+  __shared__ unsigned tile[1024];
+  __shared__ int part[4][64];
+  __shared__ int place[64];
+  const int jl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
+  const unsigned mine = j < K ? __builtin_bit_cast(unsigned, norm0[j]) : 0xffffffffu;
+  int cnt = 0;
+  for (int base = 0; base < K; base += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256)
+      tile[t] = base + t < K ? __builtin_bit_cast(unsigned, norm0[base + t]) : 0xffffffffu;
+    __syncthreads();
+    const int lim = K - base < 1024 ? K - base : 1024;
+    const int t1 = seg * 256 + 256 < lim ? seg * 256 + 256 : lim;
+    for (int t = seg * 256; t < t1; ++t) {   // same address in every lane: a broadcast
+      const unsigned o = tile[t];
+      cnt += (o < mine || (o == mine && base + t < j)) ? 1 : 0;
+    }
+  }
+  part[seg][jl] = cnt;
+  __syncthreads();
+  if (seg == 0) {
+    const int r = part[0][jl] + part[1][jl] + part[2][jl] + part[3][jl];
+    place[jl] = j < K ? r : -1;
+    if (j < K) {
+      rank[j] = r;
+      perm[r] = j;
+      norms_out[r] = norm0[j];
+    }
+  }
+  // behind the last codeword: padding norms, identity entries (never read for a real candidate)
+  for (int t = K + blockIdx.x * 256 + threadIdx.x; t < kpad; t += gridDim.x * 256) {
+    norms_out[t] = kPadNorm;
+    perm[t] = t;
+    rank[t] = t;
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (int rl = grp; rl < 64; rl += 16) {
+    const int r = place[rl];
+    if (r < 0) continue;
+    const f32x4* src = reinterpret_cast<const f32x4*>(C + (int64_t)(blockIdx.x * 64 + rl) * kD);
+    f32x4* dst = reinterpret_cast<f32x4*>(cperm + (int64_t)r * kD);
+    dst[sub] = src[sub];
+    dst[sub + 16] = src[sub + 16];
+  }
+}
+
 static int aux_norm_grid(int64_t kpad) {
   int64_t g = (kpad + 15) / 16;
   return (int)(g > 512 ? 512 : (g < 1 ? 1 : g));
@@ -1863,7 +1987,9 @@ static int aux_norm_grid(int64_t kpad) {
 
 size_t codebook_aux_scratch_bytes(int64_t k, int D) {
   const int64_t kpad = (k + kStageK - 1) / kStageK * kStageK;
-  return (size_t)kAuxSlabMax * D * 4 + (size_t)aux_norm_grid(kpad) * 2 * 4;
+  // column sums, per-workgroup maxima, and the norms in codebook order while the search order
+  // is being worked out
+  return (size_t)kAuxSlabMax * D * 4 + (size_t)512 * 2 * 4 + (aux_ordered(k, D) ? (size_t)kpad * 4 : 0);
 }
 
 // c [k][D] with D a multiple of 128 (narrower rows are padded by the caller)
@@ -1882,11 +2008,20 @@ hipError_t launch_codebook_aux(const float* c, int64_t k, int D, float* aux, cha
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int grid = aux_norm_grid(kpad);
+  const bool ordered = aux_ordered(k, D);
+  float* norm0 = ordered ? pmax + 512 * 2 : aux + kAuxNorms;
   hipLaunchKernelGGL(k_aux_norms, dim3((unsigned)grid), dim3(256), D * 4, s, c, k, D, kpad, psum,
-                     (int)n_slabs, aux, aux_mean_offset(kpad, D), pmax);
+                     (int)n_slabs, aux, norm0, aux_mean_offset(kpad, D), pmax);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_aux_max, dim3(1), dim3(64), 0, s, pmax, grid, aux);
+  e = hipGetLastError();
+  if (e != hipSuccess || !ordered) return e;
+  hipLaunchKernelGGL(k_order_codebook, dim3((unsigned)((k + 63) / 64)), dim3(256), 0, s, norm0,
+                     (int)k, (int)kpad, c, aux + kAuxNorms,
+                     reinterpret_cast<int32_t*>(aux + aux_perm_offset(kpad)),
+                     reinterpret_cast<int32_t*>(aux + aux_rank_offset(kpad)),
+                     aux + aux_cperm_offset(kpad));
   return hipGetLastError();
 }
 

@@ -29,9 +29,13 @@ struct AssignPlan {
   int64_t row_tiles, full_tiles;
   int tail_quota, max_pieces;
   int64_t tail_wgs;
+  int wide_pieces;                 // rows of 512 columns and more: every row tile is cut into this
+                                   // many pieces of tail_quota stages whose workgroups share an
+                                   // XCD (0: the line walk above)
 };
-// wide: rows of more than 128 columns (always the 8-wave geometry)
-void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, bool wide = false);
+// D: columns of a row after padding to a multiple of 128 (more than 128: always the 8-wave
+// geometry)
+void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D = kD);
 // records the partial buffer of a plan holds: two per row (one per lane half), plus
 // 2 max_pieces - 2 more for every row of the tail
 int64_t assign_part_records(const AssignPlan& p, int64_t n);
@@ -50,7 +54,23 @@ constexpr int kMaxWideD = 2048;   // widest (padded) row the search handles
 // does not fit in front
 __host__ __device__ inline int64_t aux_tail_offset(int64_t kpad) { return kAuxNorms + kpad; }
 inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? aux_tail_offset(kpad) : 0; }
-inline int64_t aux_floats(int64_t kpad, int D) { return kAuxNorms + kpad + D; }
+// Codebooks of 128 columns and kOrderMinK < k <= kOrderMaxK codewords are SEARCHED in ascending
+// order of |c_j - m|^2 (a codeword near the mean is a likelier nearest neighbour of any row, and
+// the sooner a scan meets its eventual winners, the fewer of the later tiles pass the ranking
+// gate: 1.3 points of the matrix peak at 1M rows x 10k words).  The block then also holds, behind
+// the doubled mean: perm int32 [kpad] (search position -> codeword index), rank int32 [kpad]
+// (codeword index -> search position) and the codebook in search order, float [k][128]; the norms
+// at kAuxNorms are in search order.  Only the matrix-core kernel sees search positions: k_rescore
+// translates them back as it reads the lists, and every tie is broken by codeword index as before.
+constexpr int64_t kOrderMinK = 256;
+constexpr int64_t kOrderMaxK = 16384;
+inline bool aux_ordered(int64_t k, int D) { return D == kD && k > kOrderMinK && k <= kOrderMaxK; }
+inline int64_t aux_perm_offset(int64_t kpad) { return kAuxNorms + kpad + kD; }
+inline int64_t aux_rank_offset(int64_t kpad) { return aux_perm_offset(kpad) + kpad; }
+inline int64_t aux_cperm_offset(int64_t kpad) { return aux_rank_offset(kpad) + kpad; }
+inline int64_t aux_floats(int64_t k, int64_t kpad, int D) {
+  return kAuxNorms + kpad + D + (aux_ordered(k, D) ? 2 * kpad + k * kD : 0);
+}
 // the flagged rows' second look runs on a fixed grid; cut into pieces it holds at most one
 // partial record per (row, piece) with groups x pieces <= the grid, i.e. 16 * kExactGrid records
 constexpr int kExactGrid = 1024;   // (a launch of 4096 workgroups that find nothing to do costs 3 us more)
@@ -83,18 +103,22 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
                                bool mode2, const float* thr, const PartBufs& pb, float* rowband,
                                float* wide_xc, uint32_t* zero_word, hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
+// rank (may be NULL): codeword index -> position of its norm in aux (codebooks in search order)
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
                                  const float* aux, const float* mean, int D, const int32_t* hint,
-                                 float* thr, hipStream_t s);
+                                 const int32_t* rank, float* thr, hipStream_t s);
 // merge the pieces, evaluate the two candidates as sum (x-c)^2, order, sqrt, ratio test; the
 // rows whose pair is not certain to hold the answer are appended to list [n] i32 (any order),
 // *count (cleared beforehand, see zero_word above) counts them; tickets [kExactGrid] u32 are
 // cleared for launch_exact_rows.
 // rowband != NULL (only i1 wanted, top-1): rows whose second-best value lies outside the band of
 // the best are answered from the records alone.
+// perm (may be NULL): search position -> codeword index, when the lists hold search positions.
 int64_t rescore_chunk(int64_t n);
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const float* mean, int D, const PartBufs& pb, const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          const float* mean, int D, const PartBufs& pb, const int32_t* perm,
+                          const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1,
+                          float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s);
 // search the listed rows again by direct differences and overwrite their outputs.

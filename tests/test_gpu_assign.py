@@ -173,20 +173,35 @@ def test_top1_matches_top2_and_codebook_aux():
     assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
     # its contents: mean vector, the two maxima, the mean's norm (rounded up), centred squared
     # norms, the padding to 128 (a huge finite norm: padding must never be ranked), and behind
-    # them the doubled mean the search kernel centres with
+    # them the doubled mean the search kernel centres with.  A codebook of this size is scanned
+    # in ascending order of the norms: they are stored in that order, followed by the
+    # permutation, its inverse and the codewords in scan order.
     a = aux.cpu().numpy()
     c64 = c.astype(np.float64)
     mean = c64.mean(0)
-    assert a.shape[0] == 256 + 384 + 128
+    assert a.shape[0] == 256 + 384 + 128 + 2 * 384 + 300 * 128
     assert oracle.check_close(a[:128], mean, rel=1e-6) <= 1e-6
     cn = ((c64 - a[:128].astype(np.float64)) ** 2).sum(1)
-    assert oracle.check_close(a[256:256 + 300], cn, rel=1e-5) <= 1e-5
+    perm = a[768:768 + 384].view(np.int32)
+    rank = a[768 + 384:768 + 768].view(np.int32)
+    assert sorted(perm[:300]) == list(range(300)) and np.array_equal(rank[perm[:300]], np.arange(300))
+    norms = a[256:256 + 300]
+    assert (np.diff(norms) >= 0).all()
+    ties = np.diff(norms) == 0
+    assert (np.diff(perm[:300])[ties] > 0).all()       # equal norms: by codeword index
+    assert oracle.check_close(norms, cn[perm[:300]], rel=1e-5) <= 1e-5
+    assert np.array_equal(a[768 + 768:].reshape(300, 128), c[perm[:300]])
     assert (a[256 + 300:256 + 384] > 3.1e38).all() and np.isfinite(a[256 + 300:256 + 384]).all()
+    # a codebook too small to be worth ordering keeps the plain layout
+    small = ops.codebook_aux(_dev(c[:200])).cpu().numpy()
+    assert small.shape[0] == 256 + 256 + 128
+    assert oracle.check_close(small[256:256 + 200], ((c64[:200] - small[:128].astype(np.float64)) ** 2).sum(1),
+                              rel=1e-5) <= 1e-5
     assert abs(a[128] - cn.max()) <= 1e-5 * cn.max()
     assert abs(a[129] - (c64 ** 2).sum(1).max()) <= 1e-5 * (c64 ** 2).sum(1).max()
     m_norm = np.sqrt((a[:128].astype(np.float64) ** 2).sum())
     assert m_norm <= a[130] <= m_norm * (1 + 1e-6)
-    assert np.array_equal(a[256 + 384:], 2.0 * a[:128])
+    assert np.array_equal(a[256 + 384:768], 2.0 * a[:128])
     # a narrow codebook is padded before its block is taken
     c36 = _dev(c[:, :36])
     i36, d36 = ops.assign_top1(_dev(x[:, :36]), c36, ops.codebook_aux(c36))
@@ -261,11 +276,13 @@ def test_fast_path_equals_direct_search_on_near_ties_and_duplicates():
     ci = rng.integers(0, 3, size=(500, 128)).astype(np.float32)
     _same_as_direct(xi, np.concatenate([ci, ci, ci[:100]]))
     # so many flagged rows that the second look does not cut the codebook into pieces (more
-    # 16-row groups than its grid has workgroups): every best is a three-way tie, and the first
-    # 131 072 rows are searched unsplit, so k_rescore cannot settle them from other splits' records
+    # 16-row groups than its grid has workgroups): every best is a seven-way tie (equal norms
+    # put the copies next to each other in the scan order, so at least four of them meet in one
+    # lane's list, which names three), and the first 131 072 rows are searched unsplit, so
+    # k_rescore cannot settle them from other splits' records
     xb = rng.integers(0, 2, size=(140_000, 128)).astype(np.float32)
-    cb = rng.integers(0, 2, size=(2800, 128)).astype(np.float32)
-    f1, _ = _same_as_direct(xb, np.concatenate([cb, cb, cb]))
+    cb = rng.integers(0, 2, size=(1200, 128)).astype(np.float32)
+    f1, _ = _same_as_direct(xb, np.concatenate([cb] * 7))
     assert f1 > 65536
     # single codeword, two codewords
     _same_as_direct(sift_like(100, seed=89), sift_like(1, seed=90))
@@ -456,7 +473,8 @@ def test_direct_search_vs_oracle(n, k, d):
 
 
 @pytest.mark.parametrize("n,k,d", [(3000, 600, 400), (2500, 600, 1937), (700, 70, 129),
-                                   (40_000, 300, 256), (300, 5000, 640), (1000, 40, 2048)])
+                                   (40_000, 300, 256), (300, 5000, 640), (1000, 40, 2048),
+                                   (70_000, 2100, 512)])
 def test_rows_wider_than_128_columns(n, k, d):
     """Rows of more than 128 columns are searched in 128-column slabs with the accumulators
     carried from slab to slab (the 1937-column face signatures of
