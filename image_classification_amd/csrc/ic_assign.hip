@@ -459,9 +459,13 @@ __device__ __forceinline__ void tile_epilogue_gated1(const f32x16& a, Top2& st, 
     gate = __builtin_fmaf(MODE2 ? k2 : k1, one_plus_slope, c0);
     return;
   }
-  const float m = min3f(min3f(min3f(a[0], a[1], a[2]), min3f(a[3], a[4], a[5]), min3f(a[6], a[7], a[8])),
-                        min3f(min3f(a[9], a[10], a[11]), min3f(a[12], a[13], a[14]), a[15]),
-                        __builtin_inff());
+  // the minima of five triples of registers (and the sixteenth register) on the way to the
+  // tile minimum: a tile that passes is usually passed by one candidate of one lane, so the
+  // per-register tests are asked only inside the triples whose minimum passes (six tests and
+  // three more, instead of sixteen)
+  const float t0 = min3f(a[0], a[1], a[2]), t1 = min3f(a[3], a[4], a[5]), t2 = min3f(a[6], a[7], a[8]);
+  const float t3 = min3f(a[9], a[10], a[11]), t4 = min3f(a[12], a[13], a[14]);
+  const float m = min3f(min3f(t0, t1, t2), min3f(t3, t4, a[15]), __builtin_inff());
   if (__builtin_amdgcn_ballot_w64(m < gate) != 0) {
     float k1 = st.d1, k2 = st.d2, k3 = st.d3, k4 = st.d4;
     const float g = gate;
@@ -473,14 +477,19 @@ __device__ __forceinline__ void tile_epilogue_gated1(const f32x16& a, Top2& st, 
         else insert3(k1, k2, k3, x);
       }
     } else {
+      const float tmin[5] = {t0, t1, t2, t3, t4};
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
-          // lanes that did not pass: needless, never wrong
-          const float x = key_of(a[r], r);
-          if constexpr (MODE2) insert4(k1, k2, k3, k4, x);
-          else insert3(k1, k2, k3, x);
-        }
+      for (int q = 0; q < 6; ++q) {
+        if (q < 5 && __builtin_amdgcn_ballot_w64(tmin[q < 5 ? q : 0] < g) == 0) continue;
+#pragma unroll
+        for (int r = 3 * q; r < (q < 5 ? 3 * q + 3 : 16); ++r)
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(a[r] < g) != 0, 0)) {
+            // lanes that did not pass: needless, never wrong
+            const float x = key_of(a[r], r);
+            if constexpr (MODE2) insert4(k1, k2, k3, k4, x);
+            else insert3(k1, k2, k3, x);
+          }
+      }
     }
     resolve_tiles<MODE2>(st, k1, k2, k3, k4, tile);
     gate = __builtin_fmaf(MODE2 ? k2 : k1, one_plus_slope, c0);
