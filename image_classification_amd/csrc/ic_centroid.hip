@@ -62,7 +62,11 @@ __device__ __forceinline__ int pow2_at_least(int v, int floor_) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_cent_sort_count(const int32_t* __restrict__ codes,
+// (a step of the sort is bound by its barrier, not by its compare-exchanges: 1024 threads take two
+// each instead of eight)
+constexpr int kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void k_cent_sort_count(const int32_t* __restrict__ codes,
                                                          int64_t n, int64_t k, int64_t nb,
                                                          unsigned* __restrict__ keys,
                                                          unsigned* __restrict__ tab) {
@@ -70,8 +74,8 @@ __global__ __launch_bounds__(256) void k_cent_sort_count(const int32_t* __restri
   const int64_t base = (int64_t)blockIdx.x * kBlkRows;
   const int64_t left = n - base;
   const int cnt = left < kBlkRows ? (int)left : kBlkRows;
-  const int P = pow2_at_least(cnt, 512);
-  for (int p = threadIdx.x; p < P; p += 256) {
+  const int P = pow2_at_least(cnt, 2 * kSortThreads);
+  for (int p = threadIdx.x; p < P; p += kSortThreads) {
     unsigned key = kNoKey;
     if (p < cnt) {
       const int32_t c = codes[base + p];
@@ -79,8 +83,8 @@ __global__ __launch_bounds__(256) void k_cent_sort_count(const int32_t* __restri
     }
     buf[p] = key;
   }
-  bitonic_sort_lds<256>(buf, P);
-  for (int p = threadIdx.x; p < cnt; p += 256) {
+  bitonic_sort_lds<kSortThreads>(buf, P);
+  for (int p = threadIdx.x; p < cnt; p += kSortThreads) {
     const unsigned key = buf[p];
     keys[base + p] = key;
     if (key == kNoKey) continue;
@@ -90,17 +94,29 @@ __global__ __launch_bounds__(256) void k_cent_sort_count(const int32_t* __restri
   }
 }
 
+// Per bucket: exclusive prefix over the blocks (in place) and the bucket's total.  A workgroup
+// takes 32 buckets; its eight groups of 32 threads each take an eighth of the blocks, sum it,
+// and after the exchange of the eight sums write the running prefix of their part.
 __global__ __launch_bounds__(256) void k_cent_colscan(unsigned* __restrict__ tab, int64_t nblk,
                                                       int64_t nb, int64_t* __restrict__ total) {
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ long long part[8][32];
+  const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t b = (int64_t)blockIdx.x * 32 + col;
+  const int64_t blk0 = nblk * g / 8, blk1 = nblk * (g + 1) / 8;
+  long long sum = 0;
+  if (b < nb)
+    for (int64_t blk = blk0; blk < blk1; ++blk) sum += tab[blk * nb + b];
+  part[g][col] = sum;
+  __syncthreads();
   if (b >= nb) return;
-  int64_t run = 0;
-  for (int64_t blk = 0; blk < nblk; ++blk) {
+  long long run = 0;
+  for (int gg = 0; gg < g; ++gg) run += part[gg][col];
+  for (int64_t blk = blk0; blk < blk1; ++blk) {
     const unsigned c = tab[blk * nb + b];
     tab[blk * nb + b] = (unsigned)run;  // rows of this bucket in earlier blocks (< 2^31 rows)
     run += c;
   }
-  total[b] = run;
+  if (g == 7) total[b] = run;
 }
 
 // start[b] = sum of total[0..b), start[nb] = number of valid rows; one workgroup, in place capable
@@ -159,9 +175,12 @@ __global__ __launch_bounds__(256) void k_cent_scatter(const int32_t* __restrict_
   }
 }
 
+// rows of a bucket a workgroup of k_cent_sums stages at a time: with 2048 the kernel's LDS
+// (32 KB of sums + 16 KB of keys and rows) lets three workgroups share a CU
+constexpr int kSumChunk = 2048;
 constexpr int kSumThreads = 512;
 constexpr int kSumWaves = kSumThreads / 64;
-constexpr int kRowsInFlight = 8;
+constexpr int kRowsInFlight = 16;
 
 template <bool PAIR>  // PAIR: d is even, a lane loads its two components as one 8-byte word
 __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
@@ -170,8 +189,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
     int64_t* __restrict__ pcounts) {
   __shared__ __attribute__((aligned(16))) double sums[kBucketClusters][kD];
   __shared__ long long cnt[kBucketClusters];
-  __shared__ unsigned keybuf[kBlkRows];
-  __shared__ int rowbuf[kBlkRows];
+  __shared__ unsigned keybuf[kSumChunk];
+  __shared__ int rowbuf[kSumChunk];
   __shared__ int bound[kBucketClusters + 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -187,14 +206,14 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
   if (threadIdx.x < kBucketClusters) cnt[threadIdx.x] = 0;
 
   const int64_t s0 = start[b], s1 = start[b + 1];
-  const int64_t chunks = (s1 - s0 + kBlkRows - 1) / kBlkRows;
+  const int64_t chunks = (s1 - s0 + kSumChunk - 1) / kSumChunk;
   const int64_t ch0 = chunks * r / n_ranges, ch1 = chunks * (r + 1) / n_ranges;
   const int c2 = 2 * lane;
 
   for (int64_t ch = ch0; ch < ch1; ++ch) {
-    const int64_t base = s0 + ch * kBlkRows;
+    const int64_t base = s0 + ch * kSumChunk;
     const int64_t left = s1 - base;
-    const int n_here = left < kBlkRows ? (int)left : kBlkRows;
+    const int n_here = left < kSumChunk ? (int)left : kSumChunk;
     const int P = pow2_at_least(n_here, 2 * kSumThreads);
     __syncthreads();  // previous chunk fully consumed (and the zeroing above finished)
     for (int p = threadIdx.x; p < P; p += kSumThreads) {
@@ -267,7 +286,7 @@ void centroid_plan(int64_t n, int64_t k, int d, int num_cus, CentroidPlan* p) {
   if (p->nblk < 1) p->nblk = 1;
   p->nb = (k + kBucketClusters - 1) / kBucketClusters;
   int64_t r = (4LL * num_cus + p->nb - 1) / p->nb;
-  const int64_t avg_chunks = (n / p->nb + kBlkRows - 1) / kBlkRows;
+  const int64_t avg_chunks = (n / p->nb + kSumChunk - 1) / kSumChunk;
   if (r > avg_chunks) r = avg_chunks;
   if (r > 65535) r = 65535;
   if (r < 1) r = 1;
@@ -301,9 +320,9 @@ hipError_t launch_centroid_partials(const float* x, const int32_t* codes, int64_
 
   hipError_t e = hipMemsetAsync(tab, 0, p.tab_bytes, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cent_sort_count, dim3((unsigned)p.nblk), dim3(256), 0, s, codes, n, k, p.nb,
+  hipLaunchKernelGGL(k_cent_sort_count, dim3((unsigned)p.nblk), dim3(kSortThreads), 0, s, codes, n, k, p.nb,
                      keys, tab);
-  hipLaunchKernelGGL(k_cent_colscan, dim3((unsigned)((p.nb + 255) / 256)), dim3(256), 0, s, tab,
+  hipLaunchKernelGGL(k_cent_colscan, dim3((unsigned)((p.nb + 31) / 32)), dim3(256), 0, s, tab,
                      p.nblk, p.nb, total);
   hipLaunchKernelGGL(k_cent_bucketscan, dim3(1), dim3(1024), 0, s, total, p.nb, start);
   hipLaunchKernelGGL(k_cent_scatter, dim3((unsigned)p.nblk), dim3(256), 0, s, codes, n, p.nb, keys,
