@@ -1626,6 +1626,8 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
   __shared__ uint32_t ticket;
   __shared__ float rd1[4][kExactRows], rd2[4][kExactRows];
   __shared__ int ri1[4][kExactRows], ri2[4][kExactRows];
+  __shared__ float fd1[16][kExactRows], fd2[16][kExactRows];   // the fold of a group's pieces
+  __shared__ int fi1[16][kExactRows], fi2[16][kExactRows];
   __shared__ int64_t rows[kExactRows];
   const int64_t total = list ? (int64_t)*count : n_rows;
   const int64_t n_groups = (total + kExactRows - 1) / kExactRows;
@@ -1729,14 +1731,26 @@ __global__ __launch_bounds__(256) void k_exact_top2(const float* __restrict__ X,
       __syncthreads();
       if (ticket == (uint32_t)pieces - 1u) {   // uniform in the workgroup
         __threadfence();
-        const int64_t t = g * kExactRows + threadIdx.x;
-        if (threadIdx.x < kExactRows && t < total) {
+        // sixteen threads per row, each folding every sixteenth piece (the records are read past
+        // the first-level cache, one round trip each: a single thread walking hundreds of pieces
+        // took 0.1 ms), then one thread per row folds the sixteen.  The two smallest by
+        // (distance, index) do not depend on the order of folding.
+        const int r = threadIdx.x & (kExactRows - 1), part = threadIdx.x >> 4;
+        const int64_t t = g * kExactRows + r;
+        float b1 = __builtin_inff(), b2 = __builtin_inff();
+        int k1 = -1, k2 = -1;
+        if (t < total) {
           const volatile ic_top2_rec* pr = partial + t * pieces;
-          float b1 = pr[0].d1, b2 = pr[0].d2;
-          int k1 = pr[0].i1, k2 = pr[0].i2;
-          for (int s = 1; s < pieces; ++s)
+          for (int s = part; s < pieces; s += 16)
             top2_merge_pairs(b1, k1, b2, k2, pr[s].d1, pr[s].i1, pr[s].d2, pr[s].i2);
-          write_final(fin, rows[threadIdx.x], b1, k1, b2, k2);
+        }
+        fd1[part][r] = b1; fi1[part][r] = k1;
+        fd2[part][r] = b2; fi2[part][r] = k2;
+        __syncthreads();
+        if (threadIdx.x < kExactRows && t < total) {
+          for (int q = 1; q < 16; ++q)
+            top2_merge_pairs(b1, k1, b2, k2, fd1[q][r], fi1[q][r], fd2[q][r], fi2[q][r]);
+          write_final(fin, rows[r], b1, k1, b2, k2);
         }
       }
     }
@@ -1941,7 +1955,7 @@ __global__ __launch_bounds__(256) void k_order_codebook(const float* __restrict_
                                                         int32_t* __restrict__ perm,
                                                         int32_t* __restrict__ rank,
                                                         float* __restrict__ cperm) {
-  __shared__ unsigned tile[1024];
+  __shared__ __attribute__((aligned(16))) unsigned tile[1024];
   __shared__ int part[4][64];
   __shared__ int place[64];
   const int jl = threadIdx.x & 63, seg = threadIdx.x >> 6;
@@ -1953,11 +1967,18 @@ __global__ __launch_bounds__(256) void k_order_codebook(const float* __restrict_
     for (int t = threadIdx.x; t < 1024; t += 256)
       tile[t] = base + t < K ? __builtin_bit_cast(unsigned, norm0[base + t]) : 0xffffffffu;
     __syncthreads();
-    const int lim = K - base < 1024 ? K - base : 1024;
-    const int t1 = seg * 256 + 256 < lim ? seg * 256 + 256 : lim;
-    for (int t = seg * 256; t < t1; ++t) {   // same address in every lane: a broadcast
-      const unsigned o = tile[t];
-      cnt += (o < mine || (o == mine && base + t < j)) ? 1 : 0;
+    // same address in every lane (a broadcast), four norms per read; the entries behind the
+    // last codeword hold the largest key at indices above every j, so they never count
+    const uint4* tv = reinterpret_cast<const uint4*>(tile + seg * 256);
+    const int i0 = base + seg * 256;
+#pragma unroll 4
+    for (int q = 0; q < 64; ++q) {
+      const uint4 o = tv[q];
+      const int i = i0 + 4 * q;
+      cnt += (o.x < mine || (o.x == mine && i < j)) ? 1 : 0;
+      cnt += (o.y < mine || (o.y == mine && i + 1 < j)) ? 1 : 0;
+      cnt += (o.z < mine || (o.z == mine && i + 2 < j)) ? 1 : 0;
+      cnt += (o.w < mine || (o.w == mine && i + 3 < j)) ? 1 : 0;
     }
   }
   part[seg][jl] = cnt;
