@@ -301,11 +301,11 @@ int assign_impl(void* handle, const float* x, int64_t n, const float* c, int64_t
   uint32_t* count = reinterpret_cast<uint32_t*>(ws + o_count);
   uint32_t* tickets = reinterpret_cast<uint32_t*>(ws + o_tickets);
   IC_HIP(ic::launch_top2_partial(xs, n, c_search, k, aux, mean, D, plan, mode2, thr, pb, rowband,
-                                 wide ? reinterpret_cast<float*>(ws + o_xc) : nullptr, count, s),
+                                 wide ? reinterpret_cast<float*>(ws + o_xc) : nullptr, count, perm, s),
          "distance/top-2 kernel");
   if (ev1) IC_HIP(hipEventRecord(ev1, s), "hipEventRecord");
   if (!index_only) rowband = nullptr;   // k_rescore's shortcut answers index-only calls
-  IC_HIP(ic::launch_rescore(xs, n, cs, aux, mean, D, pb, perm, rowband, plan, mode2, i1, d1, i2, d2,
+  IC_HIP(ic::launch_rescore(xs, n, cs, aux, mean, D, pb, rowband, plan, mode2, i1, d1, i2, d2,
                             ratio, mask, rec, list, count, tickets, s),
          "rescore kernel");
   IC_HIP(ic::launch_exact_rows(xs, n, cs, k, D, list, count,

@@ -590,7 +590,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ aux, int stages_total, int tail_span, int full_tiles,
     int64_t tail_units, int tail_quota, const float* __restrict__ thr, PartBufs pb,
-    float* __restrict__ rowband, uint32_t* __restrict__ zero_word) {
+    float* __restrict__ rowband, uint32_t* __restrict__ zero_word,
+    const int32_t* __restrict__ perm) {
   static_assert(XT == 1, "one 32-descriptor tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -772,14 +773,18 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     {
       const Top2& b = best[0];
       if (row < n_rows) {
+        // C is the codebook in scan order when `perm` is given (scan position -> codeword
+        // index): the lists leave the kernel in codeword indices, so that everything that
+        // follows -- merging, direct evaluation, ties by (distance, index) -- never sees positions
+        auto named = [&](int pos) { return (perm && pos >= 0) ? perm[pos] : pos; };
         ic_top2_rec rec;
-        rec.d1 = b.d1; rec.i1 = decode_candidate(b.i1, b.d1, h, K);
-        rec.d2 = b.d2; rec.i2 = decode_candidate(b.i2, b.d2, h, K);
+        rec.d1 = b.d1; rec.i1 = named(decode_candidate(b.i1, b.d1, h, K));
+        rec.d2 = b.d2; rec.i2 = named(decode_candidate(b.i2, b.d2, h, K));
         const int64_t slot = part_slot(2 * piece + h, row, N, split_row0);
         pb.rec[slot] = rec;
         pb.d3[slot] = b.d3;
         if constexpr (MODE2) {
-          pb.i3[slot] = decode_candidate(b.i3, b.d3, h, K);
+          pb.i3[slot] = named(decode_candidate(b.i3, b.d3, h, K));
           pb.d4[slot] = b.d4;
         }
         // the constant part of the row's band, for k_rescore's shortcut (same for every list)
@@ -818,7 +823,7 @@ template <int NW, int SK>
 static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int64_t k,
                                   const float* aux, const AssignPlan& plan, bool mode2,
                                   const float* thr, const PartBufs& pb, float* rowband,
-                                  uint32_t* zero_word, hipStream_t s) {
+                                  uint32_t* zero_word, const int32_t* perm, hipStream_t s) {
   const int64_t stages = (k + SK - 1) / SK;
   const int64_t tail_tiles = plan.row_tiles - plan.full_tiles;
   auto kern = !gated_variant() ? (mode2 ? k_top2_partial<kXT, NW, SK, false, true>
@@ -835,7 +840,7 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
                      (int)stages, plan.tail_span, (int)plan.full_tiles,
-                     tail_tiles * plan.tail_span, plan.tail_quota, thr, pb, rowband, zero_word);
+                     tail_tiles * plan.tail_span, plan.tail_quota, thr, pb, rowband, zero_word, perm);
   return hipGetLastError();
 }
 
@@ -1174,16 +1179,18 @@ int64_t assign_part_records(const AssignPlan& p, int64_t n) {
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const float* mean, int D, const AssignPlan& plan,
                                bool mode2, const float* thr, const PartBufs& pb, float* rowband,
-                               float* wide_xc, uint32_t* zero_word, hipStream_t s) {
+                               float* wide_xc, uint32_t* zero_word, const int32_t* perm,
+                               hipStream_t s) {
   if (!pb.rec || !pb.d3 || (mode2 && (!pb.i3 || !pb.d4))) return hipErrorInvalidValue;
+  if (D > kD && perm) return hipErrorInvalidValue;   // wide codebooks are scanned as stored
   if (D > kD)   // rowband is always filled for wide rows: it is where the kernel reads the bands
     return launch_wide(x, n, c, k, aux, mean, D, plan, mode2, thr, pb, wide_xc, rowband,
                        zero_word, s);
   if (D != kD || mean != aux) return hipErrorInvalidValue;
   if (plan.waves == 8 && plan.stage_k == 64)
-    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, s);
+    return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, perm, s);
   if (plan.waves == 16 && plan.stage_k == 128)
-    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, s);
+    return launch_geometry<16, 128>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, perm, s);
   return hipErrorInvalidValue;
 }
 
@@ -1302,7 +1309,6 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
                                                  const float* __restrict__ aux, int D,
                                                  const float* __restrict__ mean,
                                                  PartBufs pb,
-                                                 const int32_t* __restrict__ perm,
                                                  const float* __restrict__ rowband, TailGeom tail,
                                                  int64_t split_row0, int mode2, int64_t chunk,
                                                  FinalOut out, int32_t* __restrict__ list,
@@ -1335,27 +1341,16 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     ic_top2_rec b;
     float v3, u3;
   };
-  // The lists name codewords by their position in the order the matrix-core kernel scanned them;
-  // with `perm` that is not the codebook's own order, and every index is translated as it is
-  // read, so that all that follows -- merging, direct evaluation, tie-breaking by (distance,
-  // index), outputs -- happens in codeword indices.
-  auto named = [&](int idx) { return (perm && idx >= 0) ? perm[idx] : idx; };
-  auto load_rec = [&](int64_t slot) {
-    ic_top2_rec r = pb.rec[slot];
-    r.i1 = named(r.i1);
-    r.i2 = named(r.i2);
-    return r;
-  };
   const float* __restrict__ unnamed = mode2 ? pb.d4 : pb.d3;
   auto merge_lists = [&](int64_t row) {
     Head hd;
-    hd.b = load_rec(row);
+    hd.b = pb.rec[row];
     hd.v3 = pb.d3[row];
     hd.u3 = unnamed[row];
     const int ns = n_lists(row);
     for (int s = 1; s < ns; ++s) {
       const int64_t slot = part_slot(s, row, N, split_row0);
-      const ic_top2_rec o = load_rec(slot);
+      const ic_top2_rec o = pb.rec[slot];
       const float o3 = pb.d3[slot];
       hd.u3 = __builtin_fminf(hd.u3, unnamed[slot]);
       hd.v3 = third_of_union(hd.b.d1, hd.b.d2, hd.v3, o.d1, o.d2, o3);
@@ -1421,8 +1416,8 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       // evaluated
       for (int s = 0; s < ns; ++s) {
         const int64_t slot = part_slot(s, row, N, split_row0);
-        const ic_top2_rec o = load_rec(slot);
-        const int cand[3] = {o.i1, o.i2, mode2 ? named(pb.i3[slot]) : -1};
+        const ic_top2_rec o = pb.rec[slot];
+        const int cand[3] = {o.i1, o.i2, mode2 ? pb.i3[slot] : -1};
         const float val[3] = {o.d1, o.d2, mode2 ? pb.d3[slot] : 0.f};
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -1462,10 +1457,10 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       __syncthreads();
       const int64_t row = base + threadIdx.x;
       if (row < row_end) {
-        ic_top2_rec b = load_rec(row);
+        ic_top2_rec b = pb.rec[row];
         const int ns = n_lists(row);
         for (int s = 1; s < ns; ++s) {
-          const ic_top2_rec o = load_rec(part_slot(s, row, N, split_row0));
+          const ic_top2_rec o = pb.rec[part_slot(s, row, N, split_row0)];
           top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
         }
         // the gate's band of the best: everything outside the pair lies above b.d2 or was
@@ -1494,11 +1489,10 @@ int64_t rescore_chunk(int64_t n) {
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const float* mean, int D, const PartBufs& pb, const int32_t* perm,
-                          const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1,
-                          float* d1, int32_t* i2, float* d2, float ratio, uint8_t* mask,
-                          ic_top2_rec* rec, int32_t* list, uint32_t* count, uint32_t* tickets,
-                          hipStream_t s) {
+                          const float* mean, int D, const PartBufs& pb, const float* rowband,
+                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
+                          float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
+                          uint32_t* count, uint32_t* tickets, hipStream_t s) {
   // the shortcut path looks at one row per thread: whole blocks of 256 rows per workgroup
   int64_t chunk = rescore_chunk(n);
   if (rowband && chunk < 256) chunk = 256;
@@ -1509,7 +1503,7 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (mode2 && (!pb.i3 || !pb.d4)) return hipErrorInvalidValue;
   if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
   auto kern = D > kD ? k_rescore<true> : k_rescore<false>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb, perm,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb,
                      rowband, TailGeom{plan.tail_span, plan.tail_quota, plan.rows_per_wg},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);

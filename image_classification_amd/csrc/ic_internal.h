@@ -60,8 +60,8 @@ inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? aux_tail_o
 // gate: 1.3 points of the matrix peak at 1M rows x 10k words).  The block then also holds, behind
 // the doubled mean: perm int32 [kpad] (search position -> codeword index), rank int32 [kpad]
 // (codeword index -> search position) and the codebook in search order, float [k][128]; the norms
-// at kAuxNorms are in search order.  Only the matrix-core kernel sees search positions: k_rescore
-// translates them back as it reads the lists, and every tie is broken by codeword index as before.
+// at kAuxNorms are in search order.  Only the matrix-core kernel sees search positions: it
+// translates them back as it writes its lists, and every tie is broken by codeword index as before.
 constexpr int64_t kOrderMinK = 256;
 constexpr int64_t kOrderMaxK = 16384;
 inline bool aux_ordered(int64_t k, int D) { return D == kD && k > kOrderMinK && k <= kOrderMaxK; }
@@ -97,11 +97,13 @@ struct PartBufs {
 // zero_word (may be NULL): a device word the kernel clears (the flagged-row counter).
 // x [n][D], c [k][D]; mean = the mean vector inside aux (aux itself when D = 128).  Rows wider
 // than 128 columns need rowband [n] (always) and wide_xc [n][D] floats of workspace, the centred
-// copy of the rows.
+// copy of the rows.  perm (may be NULL): c is the codebook in scan order and perm [k] maps a scan
+// position to the codeword's index, which is what the lists then hold.
 hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_t k,
                                const float* aux, const float* mean, int D, const AssignPlan& plan,
                                bool mode2, const float* thr, const PartBufs& pb, float* rowband,
-                               float* wide_xc, uint32_t* zero_word, hipStream_t s);
+                               float* wide_xc, uint32_t* zero_word, const int32_t* perm,
+                               hipStream_t s);
 // thr[row] = upper bound on the kernel's value of the row's nearest codeword, from a guessed index
 // rank (may be NULL): codeword index -> position of its norm in aux (codebooks in search order)
 hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int64_t k,
@@ -113,12 +115,10 @@ hipError_t launch_hint_threshold(const float* x, int64_t n, const float* c, int6
 // cleared for launch_exact_rows.
 // rowband != NULL (only i1 wanted, top-1): rows whose second-best value lies outside the band of
 // the best are answered from the records alone.
-// perm (may be NULL): search position -> codeword index, when the lists hold search positions.
 int64_t rescore_chunk(int64_t n);
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
-                          const float* mean, int D, const PartBufs& pb, const int32_t* perm,
-                          const float* rowband, const AssignPlan& plan, bool mode2, int32_t* i1,
-                          float* d1, int32_t* i2,
+                          const float* mean, int D, const PartBufs& pb, const float* rowband,
+                          const AssignPlan& plan, bool mode2, int32_t* i1, float* d1, int32_t* i2,
                           float* d2, float ratio, uint8_t* mask, ic_top2_rec* rec, int32_t* list,
                           uint32_t* count, uint32_t* tickets, hipStream_t s);
 // search the listed rows again by direct differences and overwrite their outputs.
