@@ -103,7 +103,11 @@ int ic_row_sqnorm(void* handle, const float* x, int64_t n, int d, float* out, vo
  * instead of NULL.  It replaces the squared-norm terms scipy's _vq.vq and sklearn's
  * euclidean_distances recompute on every call.  aux [ic_codebook_aux_floats_d(k, d)] f32, device
  * (ic_codebook_aux_floats(k) is the size for d <= 128: wider rows keep their mean vector, which
- * no longer fits the block's fixed head, behind the norms). */
+ * no longer fits the block's fixed head, behind the norms).  For d <= 128 and 257 ... 16384
+ * codewords the block also holds the codebook once more, in the order the search scans it
+ * (ascending distance to the mean), with the permutation both ways: about k * 520 bytes more,
+ * included in the sizes these functions report.  A block belongs to the codebook contents it was
+ * computed from: compute it again when the codebook changes. */
 int64_t ic_codebook_aux_floats(int64_t k);
 int64_t ic_codebook_aux_floats_d(int64_t k, int d);
 int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, void* stream);
