@@ -342,6 +342,33 @@ def test_streamed_host_path_equals_device_path():
         vq(bad, c.astype(np.float64))
 
 
+def test_non_finite_codebook_entries_are_memory_safe():
+    """vq() refuses non-finite input on the host; the C ABI takes what it is given.  A codebook
+    with NaN / infinite entries (any bit pattern, the all-ones NaN included) must still be laid out
+    in a scan order that is a permutation -- the norms are ranked as bit patterns -- and every
+    index that comes back must be -1 or a codeword index."""
+    x = sift_like(5000, seed=71)
+    c = sift_like(600, seed=72)
+    c[5, 3] = np.nan
+    c[17] = np.inf
+    c[40:42].view(np.uint32)[:] = 0xFFFFFFFF
+    xd, cd = _dev(x), _dev(c)
+    aux = ops.codebook_aux(cd)
+    a = aux.cpu().numpy()
+    kpad = 640
+    perm = a[256 + kpad + 128:256 + 2 * kpad + 128].view(np.int32)
+    rank = a[256 + 2 * kpad + 128:256 + 3 * kpad + 128].view(np.int32)
+    assert sorted(perm[:600]) == list(range(600)) and np.array_equal(rank[perm[:600]], np.arange(600))
+    for out in (ops.assign_top2(xd, cd, 0.8, aux), ops.assign_top2(xd, cd, 0.8)):
+        torch.cuda.synchronize()
+        for idx in (out[0], out[2]):
+            assert bool(((idx >= -1) & (idx < 600)).all())
+    # with the damaged codewords removed the search is the ordinary one again
+    keep = np.ones(600, bool)
+    keep[[5, 17, 40, 41]] = False
+    _same_as_direct(x, c[keep])
+
+
 def test_gathered_parts_path_equals_device_path():
     # a list of per-image arrays (ragged, mixed float dtypes, one empty) is gathered by worker
     # threads into page-locked staging buffers and uploaded chunk by chunk
