@@ -117,12 +117,26 @@ def _check_pair(x, c, descriptor_search=True):
         raise ValueError("x and codebook live on different devices")
 
 
+def _check_aux(c, c_aux):
+    """The library reads the auxiliary block by the layout that belongs to the codebook's shape
+    (a copy of the codebook in scan order included): a block of any other size is refused here
+    instead of being read out of bounds on the device."""
+    if c_aux is None:
+        return
+    want = int(_lib.load().ic_codebook_aux_floats_d(c.shape[0], c.shape[1]))
+    if (c_aux.dtype != torch.float32 or c_aux.dim() != 1 or c_aux.numel() != want
+            or c_aux.device != c.device or not c_aux.is_contiguous()):
+        raise ValueError("c_aux must be the float32 block of %d elements that codebook_aux() "
+                         "returns for this codebook, on its device" % want)
+
+
 def assign_top1(x, c, c_aux=None, want_dist=True, out=None, hint=None):
     """idx[i] = argmin_j |x_i - c_j| (lowest j on ties), dist[i] = that Euclidean distance.
     `out` = (idx, dist) preallocated contiguous device tensors (views are fine).
     `hint` = int32 [n] guess of idx (e.g. the labels of the previous k-means iteration): same
     result, less ranking work when the guess is good."""
     _check_pair(x, c)
+    _check_aux(c, c_aux)
     dev = _dev_index(x)
     n = x.shape[0]
     if out is not None:
@@ -149,6 +163,7 @@ def assign_top1_static(x, c, c_aux, out):
     only).  `out` = (idx int32 [n], dist float32 [n] or None), preallocated by the caller.  Raises
     when the input needs more scratch than the static buffer holds."""
     _check_pair(x, c)
+    _check_aux(c, c_aux)
     dev = _dev_index(x)
     idx, dist = out
     rc = _lib.load().ic_assign_top1_static(_lib.handle(dev), _ptr(x), x.shape[0], _ptr(c),
@@ -162,6 +177,7 @@ def assign_top2(x, c, ratio=0.8, c_aux=None, want_mask=True, out=None):
     """Two nearest rows of c per row of x, ascending (distance, index), and the ratio-test mask.
     `out` = (i1, d1, i2, d2, mask) preallocated contiguous device tensors."""
     _check_pair(x, c)
+    _check_aux(c, c_aux)
     dev = _dev_index(x)
     n = x.shape[0]
     if out is not None:
@@ -603,6 +619,7 @@ def _to_host_staged(t, nbytes):
 def assign_top2_rec(x, c, c_aux=None):
     """Same search, packed as [n, 4] int32 words = ic_top2_rec {d1, i1, d2, i2} per row."""
     _check_pair(x, c)
+    _check_aux(c, c_aux)
     dev = _dev_index(x)
     n = x.shape[0]
     rec = torch.empty((n, 4), dtype=torch.int32, device=x.device)

@@ -562,6 +562,12 @@ def test_errors_are_loud():
         ops.assign_top1(_dev(np.zeros((4, 2100))), _dev(np.zeros((3, 2100))))
     with pytest.raises(ValueError):
         ops.assign_top1(x.cpu(), x)
+    # an auxiliary block that belongs to a codebook of another shape is refused before any launch
+    c300, c400 = _dev(sift_like(300, seed=1)), _dev(sift_like(400, seed=2))
+    with pytest.raises(ValueError, match="c_aux"):
+        ops.assign_top1(x, c400, ops.codebook_aux(c300))
+    with pytest.raises(ValueError, match="c_aux"):
+        ops.assign_top2(x, c400, 0.8, ops.codebook_aux(c300)[:-1])
 
 
 def test_reserved_workspace_is_not_reallocated():
