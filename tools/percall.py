@@ -28,3 +28,28 @@ for _ in range(300):
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(28)
+
+# the reference's per-image step: Step("feat_ext", lm.bow, 'extract') on one image
+# (vision/logo_recognition/matching_flow.py:22): BagOfWords.extract([image]) -> (descs, hist[1, K])
+from image_classification_amd import BagOfWords  # noqa: E402
+
+
+class _Pre(object):
+    def extract(self, image_list):
+        return [([(0.0, 0.0)] * 1000, x) for _ in image_list]
+
+
+bow = BagOfWords(_Pre(), vocab=c)
+for _ in range(20):
+    bow.extract([0])
+t0 = time.perf_counter()
+for _ in range(300):
+    bow.extract([0])
+print("BagOfWords.extract([one image of 1000 descriptors]) x 10000 words: %.3f ms per call"
+      % ((time.perf_counter() - t0) / 300 * 1e3))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(300):
+    bow.extract([0])
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
