@@ -74,8 +74,7 @@ class HipBackend(object):
     def assign_top1_parts(self, parts, cb, want_dist=True):
         total = sum(p.shape[0] for p in parts)
         if total <= ops.HOST_CHUNK_ROWS // 4:
-            x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
-            return self.assign_top1(self.f32(x_np), cb, want_dist)
+            return self.assign_top1(ops.upload_parts(parts, self.device), cb, want_dist)
         return ops.assign_from_host_parts(parts, cb.c, cb.aux, top2=False, want_dist=want_dist)
 
     def quantize_parts(self, parts, offsets, cb, k, norm="l1", power=0.5):
@@ -95,8 +94,7 @@ class HipBackend(object):
     def assign_top2_parts(self, parts, cb, ratio=0.8):
         total = sum(p.shape[0] for p in parts)
         if total <= ops.HOST_CHUNK_ROWS // 4:
-            x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
-            return self.assign_top2(self.f32(x_np), cb, ratio)
+            return self.assign_top2(ops.upload_parts(parts, self.device), cb, ratio)
         return ops.assign_from_host_parts(parts, cb.c, cb.aux, top2=True, ratio=ratio)
 
     # -- operators -----------------------------------------------------------------------------

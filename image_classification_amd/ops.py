@@ -280,7 +280,7 @@ def _gather_thread():
     return _gatherer
 
 
-def _gather_rows(dst, jobs, d):
+def _gather_rows(dst, jobs, d, threads=None):
     """dst (page-locked float32 tensor) <- the row ranges (array, lo, hi) of `jobs`, one after the
     other; the arrays are C-contiguous float32 or float64."""
     n = len(jobs)
@@ -292,8 +292,49 @@ def _gather_rows(dst, jobs, d):
         elems[j] = (hi - lo) * d
         kind[j] = p.dtype == _F64
     rc = _lib.load().ic_host_gather_f32(dst.data_ptr(), src.ctypes.data, elems.ctypes.data,
-                                        kind.ctypes.data, n, GATHER_THREADS)
+                                        kind.ctypes.data, n, threads or GATHER_THREADS)
     _lib.check(rc, "ic_host_gather_f32")
+
+
+_small_stage = {}                 # pid -> [page-locked buffer, event of its last upload]
+SMALL_STAGE_BYTES = 16 << 20
+
+
+def upload_parts(parts, device):
+    """float32 device tensor [sum n_i, d] of a short list of host arrays (the candidates of one
+    RobustMatcher.match call, the images of one small extract call): the rows are laid into a
+    page-locked buffer by the native gather and leave it in one asynchronous copy on the current
+    stream.  np.concatenate followed by a copy from pageable memory costs the caller about twice
+    the link time of the rows (0.17 ms for 5 MB), during which it cannot enqueue anything."""
+    d = parts[0].shape[1]
+    n = 0
+    own = False
+    for i, p in enumerate(parts):
+        if p.ndim != 2 or p.shape[1] != d:
+            raise ValueError("dimension mismatch among the parts: %s vs %d columns" % (p.shape, d))
+        n += p.shape[0]
+        if not p.flags.c_contiguous or p.dtype.char not in "fd":
+            if not own:
+                parts, own = list(parts), True
+            parts[i] = np.ascontiguousarray(p, dtype=np.float32)
+    if n * d * 4 > SMALL_STAGE_BYTES or n == 0:
+        x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        return as_device_f32(x_np, device)
+    with _staging_lock:
+        st = _small_stage.get(os.getpid())
+        if st is None:
+            # (a buffer inherited from a parent process is left alone: it is not this process's
+            # to free)
+            st = _small_stage[os.getpid()] = [
+                torch.empty(SMALL_STAGE_BYTES // 4, dtype=torch.float32).pin_memory(), None]
+        if st[1] is not None:
+            st[1].synchronize()           # the previous upload has left the buffer
+        _gather_rows(st[0], [(p, 0, p.shape[0]) for p in parts if p.shape[0]], d, threads=2)
+        xd = torch.empty((n, d), dtype=torch.float32, device=device)
+        xd.copy_(st[0][:n * d].view(n, d), non_blocking=True)
+        st[1] = torch.cuda.Event()
+        st[1].record(torch.cuda.current_stream(device))
+    return xd
 
 
 def assign_from_host_parts(parts, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,

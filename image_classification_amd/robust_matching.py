@@ -26,6 +26,7 @@ candidate when given.
 from logging import getLogger
 
 import numpy as np
+import torch
 
 from .backend import default_backend
 
@@ -107,12 +108,14 @@ class RobustMatcher(object):
         return (ransac_num_iterations(self.ransac_max_iter, self.ransac_prob, self.inlier_r),
                 MIN_INLIERS_TH, True, False)
 
-    def match_and_verify(self, query, image_list):
+    def match_and_verify(self, query, image_list, want_matches=True):
         """The whole of `match` on the device.  Returns one dict per candidate with `n_matches`,
-        `inliers`, `matches_q`, `matches_im` (int64 rows) and `mask` (uint8 per match)."""
+        `inliers` and -- unless `want_matches` is false, which spares three downloads --
+        `matches_q`, `matches_im` (int64 rows) and `mask` (uint8 per match)."""
         empty_i = np.empty(0, dtype=np.int64)
-        out = [dict(n_matches=0, inliers=0, matches_q=empty_i, matches_im=empty_i,
-                    mask=np.empty(0, dtype=np.uint8)) for _ in image_list]
+        empty_m = np.empty(0, dtype=np.uint8)
+        out = [dict(n_matches=0, inliers=0, matches_q=empty_i, matches_im=empty_i, mask=empty_m)
+               for _ in image_list]
         use = [n for n, img in enumerate(image_list) if img.desc_rows > self.min_points]
         if not use:
             return out
@@ -128,26 +131,45 @@ class RobustMatcher(object):
             rows.append(rows[-1] + parts[-1].shape[0])
         i1, _d1, _i2, _d2, mask = b.assign_top2_parts(parts, b.codebook(query.descriptors),
                                                    ratio=self.knn_thresh)
-        kp_rows = b.f64(np.ascontiguousarray(np.concatenate(kps)))
-        kp_q = b.f64(np.ascontiguousarray(np.asarray(query.keypoints, dtype=np.float64).reshape(-1, 2)))
-        out_off, match_q, match_im, pts = b.compact_matches(mask, i1, b.i64(rows), kp_q, kp_rows)
+        # the keypoints of both sides and the candidates' row offsets go up in ONE copy (a copy
+        # from pageable memory blocks the caller until it has happened; three of them cost more
+        # than the kernels of a per-box call)
+        kq = np.asarray(query.keypoints, dtype=np.float64).reshape(-1, 2)
+        n_q, n_r = kq.shape[0], rows[-1]
+        host = np.empty(2 * n_q + 2 * n_r + len(rows), dtype=np.float64)
+        host[:2 * n_q] = kq.reshape(-1)
+        at = 2 * n_q
+        for kp in kps:
+            host[at:at + kp.size] = kp.reshape(-1)
+            at += kp.size
+        host[at:] = rows               # exact: row counts are far below 2^53
+        dev = b.f64(host)
+        kp_q = dev[:2 * n_q].view(n_q, 2)
+        kp_rows = dev[2 * n_q:2 * n_q + 2 * n_r].view(n_r, 2)
+        row_off = dev[2 * n_q + 2 * n_r:].to(torch.int64)
+        out_off, match_q, match_im, pts = b.compact_matches(mask, i1, row_off, kp_q, kp_rows)
         n_iter, min_inliers, mean_rule, cv_rules = self._ransac_params()
         seed = int(np.random.randint(0, 2 ** 31 - 1))
         _H, n_inl, _err, _it, in_mask = b.ransac_homography(
             pts, out_off, n_iter, float(self.ransac_th), None, seed, min_inliers, mean_rule,
             cv_rules)
-        out_off = out_off.cpu().numpy()
-        n_inl = n_inl.cpu().numpy()
-        total = int(out_off[-1])
-        match_q = match_q[:total].cpu().numpy().astype(np.int64)
-        match_im = match_im[:total].cpu().numpy().astype(np.int64)
-        in_mask = in_mask[:total].cpu().numpy()
+        # offsets and inlier counts come down together
+        small = torch.cat([out_off, n_inl.to(torch.int64)]).cpu().numpy()
+        out_off, n_inl = small[:len(use) + 1], small[len(use) + 1:]
+        if want_matches:
+            total = int(out_off[-1])
+            match_q = match_q[:total].cpu().numpy().astype(np.int64)
+            match_im = match_im[:total].cpu().numpy().astype(np.int64)
+            in_mask = in_mask[:total].cpu().numpy()
         for slot, n in enumerate(use):
             lo, hi = int(out_off[slot]), int(out_off[slot + 1])
             verified = (hi - lo) > self.min_matches
-            out[n] = dict(n_matches=hi - lo, inliers=int(n_inl[slot]) if verified else 0,
-                          matches_q=match_q[lo:hi], matches_im=match_im[lo:hi],
-                          mask=in_mask[lo:hi] if verified else np.empty(0, dtype=np.uint8))
+            res = dict(n_matches=hi - lo, inliers=int(n_inl[slot]) if verified else 0,
+                       matches_q=empty_i, matches_im=empty_i, mask=empty_m)
+            if want_matches:
+                res.update(matches_q=match_q[lo:hi], matches_im=match_im[lo:hi],
+                           mask=in_mask[lo:hi] if verified else empty_m)
+            out[n] = res
         return out
 
     def match(self, query, image_list):
@@ -162,7 +184,8 @@ class RobustMatcher(object):
         if self.homography_fn is not None:
             return self._match_with_callable(query, image_list)
         img_scores = []
-        for img, res in zip(image_list, self.match_and_verify(query, image_list)):
+        # (the match lists are only looked at in debug mode)
+        for img, res in zip(image_list, self.match_and_verify(query, image_list, self.debug)):
             if self.debug:
                 self.query_kpts.append(query.keypoints[res["matches_q"]])
                 self.imgs_kpts.append(img.keypoints[res["matches_im"]])
