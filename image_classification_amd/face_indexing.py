@@ -14,6 +14,8 @@ Mirrors vision/facerec/face_indexing.py:131-170 and the distance re-rank at :468
 The LSH tables, the database access and the signature extraction of that module are not part of
 this path.
 """
+import os
+
 import numpy as np
 
 from .backend import default_backend
@@ -70,14 +72,43 @@ class KMeansHashing(object):
         self.distrib = distrib
         self._backend = backend
 
+    # A face is hashed against every table, one call each (vision/facerec/face_indexing.py:
+    # 139-143 through FaceIndex): the codebook is therefore held as a private read-only copy whose
+    # device copy is made once, instead of being looked up by a hash of its 4.6 MB (600 x 1937
+    # float64) on every call.  Assigning `h.codebook = other` replaces it.
+    @property
+    def codebook(self):
+        return self._codebook.view()
+
+    @codebook.setter
+    def codebook(self, value):
+        held = np.array(value, copy=True)
+        held.setflags(write=False)
+        self._codebook = held
+        self._resident = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_resident"] = None          # device memory does not travel
+        return state
+
+    def _cb(self):
+        b = self._backend or default_backend()
+        key = (os.getpid(), id(b))
+        got = getattr(self, "_resident", None)
+        if got is None or got[0] != key:
+            got = self._resident = (key, b.codebook(self._codebook))
+        return got[1]
+
     def get_hash(self, feature):
-        feature = np.reshape(feature, (1, self.codebook.shape[1]))
-        code, _dist = vq(feature, self.codebook, backend=self._backend)
+        feature = np.reshape(feature, (1, self._codebook.shape[1]))
+        code, _dist = vq(feature, self._codebook, backend=self._backend, resident=self._cb())
         return str(code[0])
 
     def get_hashes(self, features):
         """Hashes of many signatures in one device call (the reference hashes them one by one)."""
-        code, _dist = vq(np.asarray(features), self.codebook, backend=self._backend)
+        code, _dist = vq(np.asarray(features), self._codebook, backend=self._backend,
+                         resident=self._cb())
         return [str(c) for c in code]
 
     @classmethod

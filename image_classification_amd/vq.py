@@ -28,8 +28,12 @@ def _as_2d(a, name):
     return a
 
 
-def vq(obs, code_book, check_finite=True, backend=None):
-    """(code int32 [M], dist [M]) -- index of and Euclidean distance to the nearest code."""
+def vq(obs, code_book, check_finite=True, backend=None, resident=None):
+    """(code int32 [M], dist [M]) -- index of and Euclidean distance to the nearest code.
+
+    `resident`: the backend's device-resident form of `code_book` (`backend.codebook(code_book)`),
+    for callers that hold a code book nobody else can edit and search it call after call: the
+    lookup of the device copy -- a hash over every byte of `code_book` -- is then skipped."""
     obs_a = np.asarray(obs)
     cb_a = np.asarray(code_book)
     if obs_a.ndim != cb_a.ndim:
@@ -49,7 +53,7 @@ def vq(obs, code_book, check_finite=True, backend=None):
     # code book, a row holds an inf or NaN exactly when its distance is not finite.
     big = obs_a.size > (1 << 22)
     b = backend or default_backend()
-    cbk = b.codebook(cb_a)
+    cbk = resident if resident is not None else b.codebook(cb_a)
     if check_finite:
         # the code book's verdict is remembered with its device copy (one scan per code book, not
         # one per call)

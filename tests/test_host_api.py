@@ -364,6 +364,21 @@ def test_face_index_kmeans_hashing_and_rerank(backend):
         hashes = t.get_hashes(data[:50])
         assert hashes == [str(c) for c in code[:50]]
         assert t.get_hash(data[7]) == str(code[7])
+    # the table's codebook is a private copy with a device copy made once: editing the array it
+    # was built from changes nothing, in-place edits are refused, assignment replaces it
+    src = np.array(tables[0].codebook)
+    t = fi.KMeansHashing(src, tables[0].distrib, backend=backend)
+    before = t.get_hashes(data[:30])
+    src[:] = src[::-1].copy()
+    assert t.get_hashes(data[:30]) == before
+    with pytest.raises(ValueError):
+        t.codebook[0, 0] = 1.0
+    t.codebook = src
+    assert t.get_hashes(data[:30]) == [str(c) for c in oracle.vq(data[:30], src)[0]]
+    import pickle
+    t2 = pickle.loads(pickle.dumps(t))
+    t2._backend = backend
+    assert t2.get_hash(data[3]) == t.get_hash(data[3])
     # labels that do not start at 0 / miss the top cluster: scipy.stats.histogram's default limits
     lab = np.array([2, 2, 3, 5, 5, 5, 6])
     got = fi._label_histogram(lab, 8, backend)
