@@ -3,7 +3,7 @@
 The reference builds it in `KnnTrainer.train` (vision/logo_recognition/knn_training.py:34-60):
 bag-of-words histograms of the training logos become the rows of a `KNNScikit`.  That class is
 orchestration only -- it calls `bow.extract` and `KNNScikit.train` -- so it keeps working
-unchanged on top of this package once its two imports point here (INTEGRATION.md); what this
+unchanged on top of this package once its two imports point here; what this
 module offers instead is the same step as two functions plus a pickle-free on-disk form.
 """
 import numpy as np

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The plain bench line of every workload (no profiler attached): tools/bench_lines.sh <round tag>
+# The plain bench line of every workload (no profiler attached): tools/bench_lines.sh <tag>
 # writes gpurun_out/<tag>_line_<workload>.json; the default workload runs as the driver runs it
 # (CPU baseline, parity block and the communicating sub-records included).
 set -e

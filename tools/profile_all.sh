@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for every bench workload (kernel trace + stats, then the --pmc passes), and
-# the plain bench line of each: tools/profile_all.sh <round tag, e.g. r03>
+# the plain bench line of each: tools/profile_all.sh <tag>
 set -e
 tag=$1
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
