@@ -342,6 +342,19 @@ def test_streamed_host_path_equals_device_path():
         vq(bad, c.astype(np.float64))
 
 
+@pytest.mark.parametrize("k", [256, 257, 16384, 16385])
+def test_scan_order_boundaries_equal_the_direct_search(k):
+    """Codebooks of 257 ... 16384 words are scanned in ascending order of their distance to the
+    mean, smaller and larger ones as stored: on both sides of both limits the answer is the direct
+    search's, with a few codewords duplicated so that ties must go to the lowest codeword index."""
+    rng = np.random.default_rng(k)
+    c = sift_like(k, seed=300 + k % 7)
+    dup = rng.integers(0, k, 12)
+    c[dup[:6]] = c[dup[6:]]
+    x = np.concatenate([sift_like(2500, seed=k % 11), c[dup] + 0.0])      # exact hits on duplicates
+    _same_as_direct(x, c)
+
+
 def test_non_finite_codebook_entries_are_memory_safe():
     """vq() refuses non-finite input on the host; the C ABI takes what it is given.  A codebook
     with NaN / infinite entries (any bit pattern, the all-ones NaN included) must still be laid out
