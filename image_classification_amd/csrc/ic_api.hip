@@ -501,6 +501,20 @@ int ic_debug_flagged(void* handle, uint32_t* count) {
   return IC_OK;
 }
 
+int ic_debug_plan(int64_t n, int64_t k, int d, int num_cus, int64_t* out) {
+  if (!out || n < 1 || n >= 0x7fffffffLL || k < 1 || k > 0x7fffffffLL || d < 1 ||
+      d > ic::kMaxWideD || num_cus < 1)
+    return fail(IC_EINVAL, "ic_debug_plan: bad argument");
+  const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
+  ic::AssignPlan p;
+  ic::assign_plan(n, k, num_cus, &p, D);
+  const int64_t v[12] = {p.waves, p.stage_k, p.rows_per_wg, p.stages, p.tail_span, p.row_tiles,
+                         p.full_tiles, p.tail_quota, p.max_pieces, p.tail_wgs, p.wide_pieces,
+                         ic::assign_part_records(p, n)};
+  for (int i = 0; i < 12; ++i) out[i] = v[i];
+  return IC_OK;
+}
+
 int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                    const float* c_aux, int32_t* idx, float* dist, void* stream) {
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1: idx is NULL");

@@ -117,6 +117,15 @@ int ic_codebook_aux(void* handle, const float* c, int64_t k, int d, float* aux, 
  * the device word `count`; NULL switches it off. */
 int ic_debug_flagged(void* handle, uint32_t* count); /* `count` must stay valid until reset */
 
+/* Test hook, no counterpart in the reference, host arithmetic only (no handle, no GPU): how a
+ * search of n rows x k codewords x d columns would be cut into workgroups on a device with
+ * `num_cus` compute units.  out [12] int64: waves per workgroup, codewords per stage, rows per
+ * workgroup, stages, places a row tile of the tail takes in the line of (row tile, stage) units,
+ * row tiles, row tiles scanned whole, stages per workgroup of the tail, most pieces a row tile
+ * falls into, workgroups of the tail, pieces per row tile of the wide search (0: none), records
+ * of the partial buffer.  The CPU tests replay the kernels' index arithmetic against it. */
+int ic_debug_plan(int64_t n, int64_t k, int d, int num_cus, int64_t* out);
+
 /* Nearest codeword per row: idx[i] = argmin_j ||x_i - c_j|| (lowest j on ties), dist[i] = that
  * Euclidean distance.  Replaces scipy.cluster.vq.vq at model/features.py:1166 and
  * vision/facerec/face_indexing.py:141, and argmin(euclidean_distances(..., squared=True)) at

@@ -1,0 +1,144 @@
+"""The decomposition of a search into workgroups, checked on the CPU: ic_debug_plan gives the
+plan the library would launch, and the kernels' own index arithmetic (k_top2_partial /
+k_top2_wide: which units of the line of (row tile, stage) pairs a workgroup walks, which piece of
+its row tile that is, which record slot a piece writes) is replayed here in Python.  Every stage
+of every row tile must be scanned exactly once, pieces must be numbered 0 .. pieces-1 without
+gaps, no piece index may reach max_pieces, and the record slots of all (row, list) pairs must be
+distinct and inside the partial buffer."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from image_classification_amd import _lib
+
+FIELDS = ("waves", "stage_k", "rows_per_wg", "stages", "tail_span", "row_tiles", "full_tiles",
+          "tail_quota", "max_pieces", "tail_wgs", "wide_pieces", "records")
+
+
+def plan(n, k, d=128, cus=256):
+    out = (ctypes.c_int64 * 12)()
+    rc = _lib.load().ic_debug_plan(n, k, d, cus, out)
+    assert rc == 0, _lib.last_error()
+    return dict(zip(FIELDS, (int(v) for v in out)))
+
+
+def walk(p, n):
+    """[(row tile, first stage, stages, piece)] of every workgroup run, as the kernels derive them
+    from blockIdx."""
+    runs = []
+    S, span, q = p["stages"], p["tail_span"], p["tail_quota"]
+    full = p["full_tiles"]
+    if p["wide_pieces"]:
+        P = p["wide_pieces"]
+        grid = (p["row_tiles"] + 7) // 8 * 8 * P
+        for g in range(grid):
+            xcd, place = g & 7, g >> 3
+            tile = place // P * 8 + xcd
+            piece = place % P
+            st = piece * q
+            left = min(q, S - st)
+            if tile * p["rows_per_wg"] >= n:
+                continue
+            assert left >= 1
+            runs.append((tile, st, left, piece))
+        return runs
+    for g in range(full):
+        runs.append((g, 0, S, 0))
+    tail_units = (p["row_tiles"] - full) * span
+    for g in range(p["tail_wgs"]):
+        u = g * q
+        tt = u // span
+        rest = tail_units - u
+        tile = full + tt
+        st = u - tt * span
+        left = min(rest, q)
+        if span != S:
+            left = min(left, S - st)
+        piece = g - tt * span // q
+        while left > 0:
+            item = min(S - st, left)
+            assert item >= 1
+            runs.append((tile, st, item, piece))
+            left -= item
+            tile, st, piece = tile + 1, 0, 0
+    return runs
+
+
+def check(n, k, d=128, cus=256):
+    p = plan(n, k, d, cus)
+    S = p["stages"]
+    assert p["rows_per_wg"] == p["waves"] * 32 and p["stage_k"] in (64, 128)
+    assert S == -(-k // p["stage_k"]) and p["row_tiles"] == -(-n // p["rows_per_wg"])
+    assert 0 <= p["full_tiles"] <= p["row_tiles"]
+    covered = np.zeros((p["row_tiles"], S), dtype=np.int32)
+    pieces = [set() for _ in range(p["row_tiles"])]
+    for tile, st, cnt, piece in walk(p, n):
+        assert 0 <= tile < p["row_tiles"] and 0 <= st and st + cnt <= S
+        covered[tile, st:st + cnt] += 1
+        assert piece not in pieces[tile], "two runs write the same records"
+        pieces[tile].add(piece)
+    assert (covered == 1).all(), "a stage is scanned %s times" % sorted(set(covered.ravel()))
+    split_row0 = min(n, p["full_tiles"] * p["rows_per_wg"])
+    for tile, got in enumerate(pieces):
+        assert got == set(range(len(got))) and len(got) <= p["max_pieces"]
+        if tile < p["full_tiles"]:
+            assert got == {0}
+        else:
+            # what k_rescore takes the number of lists of a tail row tile to be
+            tt = tile - p["full_tiles"]
+            span, q = p["tail_span"], p["tail_quota"]
+            first = tt * span // q
+            assert len(got) == ((tt + 1) * span - 1) // q - first + 1
+    # record slots (part_slot): lists 0 and 1 for every row, the others only for the tail's rows
+    assert p["records"] == 2 * n + (2 * p["max_pieces"] - 2) * (n - split_row0)
+    return p
+
+
+@pytest.mark.parametrize("n,k,d", [
+    (100_000, 1000, 128),        # one partly filled round: stream-K runs across row tiles
+    (1_000_000, 10_000, 128),    # seven whole rounds and a tail
+    (4000, 2_000_000 // 64, 128),  # few row tiles, long codebook: aligned pieces (scaled down)
+    (1, 1, 128), (31, 33, 128), (513, 64, 128), (256, 8192, 128), (512, 8191, 128),
+    (100_000, 600, 1937), (1000, 600, 1937), (70_000, 2100, 512), (300, 5000, 640),
+    (40_000, 300, 256), (2500, 600, 2048), (1_000_000, 256, 128), (140_000, 8400, 128),
+])
+def test_named_shapes(n, k, d):
+    check(n, k, d)
+
+
+def test_random_shapes():
+    rng = np.random.default_rng(12)
+    for _ in range(400):
+        n = int(rng.choice([1, 17, 255, 256, 257, 5000, 70_000, 131_072, 400_000])) + int(rng.integers(0, 600))
+        k = int(rng.choice([1, 2, 63, 64, 65, 700, 4000, 8191, 8192, 20_000])) + int(rng.integers(0, 130))
+        d = int(rng.choice([128, 128, 128, 36, 129, 256, 512, 640, 1024, 1937, 2048]))
+        cus = int(rng.choice([256, 256, 304, 64, 1]))
+        if n * -(-k // 64) > 3_000_000:      # keep the coverage matrix small
+            n = max(1, 3_000_000 // -(-k // 64))
+        check(n, k, d, cus)
+
+
+def test_wide_rows_share_an_xcd():
+    # the pieces of a row tile of the wide search sit at consecutive places of one XCD
+    p = plan(100_000, 600, 1937)
+    P = p["wide_pieces"]
+    assert P == 10 and p["tail_quota"] == 1 and p["full_tiles"] == 0
+    by_tile = {}
+    grid = (p["row_tiles"] + 7) // 8 * 8 * P
+    for g in range(grid):
+        tile = (g >> 3) // P * 8 + (g & 7)
+        by_tile.setdefault(tile, []).append(g)
+    for tile, ids in by_tile.items():
+        assert len({g & 7 for g in ids}) == 1
+        places = sorted(g >> 3 for g in ids)
+        assert places == list(range(places[0], places[0] + P))
+
+
+def test_bad_arguments_are_refused():
+    out = (ctypes.c_int64 * 12)()
+    lib = _lib.load()
+    assert lib.ic_debug_plan(0, 10, 128, 256, out) != 0
+    assert lib.ic_debug_plan(10, 0, 128, 256, out) != 0
+    assert lib.ic_debug_plan(10, 10, 4096, 256, out) != 0
+    assert lib.ic_debug_plan(10, 10, 128, 256, None) != 0
