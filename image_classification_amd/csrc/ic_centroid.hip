@@ -11,9 +11,10 @@
 //   P2 k_cent_colscan     per bucket: exclusive prefix over blocks (in place) and bucket total
 //      k_cent_bucketscan  exclusive prefix over bucket totals
 //   P3 k_cent_scatter     (row, code) of every row -> its slot in bucket order (stable)
-//   P4 k_cent_sums        workgroup = (bucket of 32 clusters, range of the bucket's 4096-row
-//                         chunks): chunk sorted by (cluster, position) in LDS, each wave sums the
-//                         rows of its clusters, 8 row loads in flight; float64 sums in LDS
+//   P4 k_cent_sums        workgroup = (bucket of 32 clusters, range of the bucket's 2048-row
+//                         chunks): the chunk's rows grouped by cluster with wave ballots (row
+//                         order kept), each wave sums the rows of its clusters, 16 row loads in
+//                         flight; float64 sums in LDS
 //   P5 k_centroid_reduce  (ic_reduce.hip) folds the ranges in ascending order
 // Every word has one writer between two barriers, and the order of every summation is fixed by
 // the row order, so results are bit-reproducible.
@@ -176,12 +177,24 @@ __global__ __launch_bounds__(256) void k_cent_scatter(const int32_t* __restrict_
 }
 
 // rows of a bucket a workgroup of k_cent_sums stages at a time: with 2048 the kernel's LDS
-// (32 KB of sums + 16 KB of keys and rows) lets three workgroups share a CU
+// (32 KB of sums + 14 KB of rows, positions and cluster numbers) lets three workgroups share a CU
 constexpr int kSumChunk = 2048;
 constexpr int kSumThreads = 512;
 constexpr int kSumWaves = kSumThreads / 64;
 constexpr int kRowsInFlight = 16;
 
+// Workgroup = (bucket of 32 clusters, range of the bucket's chunks, slab of 128 columns).  A
+// chunk's (row, cluster) pairs arrive in partition order, i.e. ascending rows inside the bucket.
+// They are grouped by cluster without a sort: wave w owns the clusters lc with lc % 8 == w and, for
+// each of them, walks the chunk's cluster numbers 64 at a time -- a ballot marks its cluster's
+// positions, the set bits below a lane give the lane's place -- first to count, then (after an
+// exclusive scan over the 32 counts) to write the positions of the cluster's rows, in row order,
+// into its stretch of `list`.  The same wave then sums that stretch: 16 row loads in flight,
+// float64 accumulators, ascending rows.  (A bitonic sort of the chunk by (cluster, position) did
+// the grouping before: 55 barrier-bound steps for a 610-row chunk, 0.249 against 0.228 ms at
+// 1.25 M rows x 65 536 clusters.  Walking a wave's four clusters as ONE run of 16-row batches,
+// with the accumulators handed over wherever the cluster changes, saves three of eight batches
+// and measured 0.257 ms: the hand-over inside the unrolled adds costs more than the batches.)
 template <bool PAIR>  // PAIR: d is even, a lane loads its two components as one 8-byte word
 __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
     const float* __restrict__ X, int d, int64_t k, const RowCode* __restrict__ perm,
@@ -189,16 +202,17 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
     int64_t* __restrict__ pcounts) {
   __shared__ __attribute__((aligned(16))) double sums[kBucketClusters][kD];
   __shared__ long long cnt[kBucketClusters];
-  __shared__ unsigned keybuf[kSumChunk];
   __shared__ int rowbuf[kSumChunk];
-  __shared__ int bound[kBucketClusters + 1];
+  __shared__ unsigned short list[kSumChunk];
+  __shared__ unsigned char code5[kSumChunk];
+  __shared__ int ccount[kBucketClusters], cstart[kBucketClusters];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t b = blockIdx.x;
   const int64_t r = blockIdx.y;
   const int64_t c0 = b << kBucketShift;
-  // rows wider than 128 columns: workgroup z sums columns [128 z, 128 z + 128) (the partition is
-  // sorted again by each, which costs little next to the row gathers)
+  // rows wider than 128 columns: workgroup z sums columns [128 z, 128 z + 128) (the grouping is
+  // done again by each, which costs little next to the row gathers)
   const int col0 = (int)blockIdx.z * kD;
   const int dw = d - col0 < kD ? d - col0 : kD;   // columns of this slab
 
@@ -209,29 +223,61 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
   const int64_t chunks = (s1 - s0 + kSumChunk - 1) / kSumChunk;
   const int64_t ch0 = chunks * r / n_ranges, ch1 = chunks * (r + 1) / n_ranges;
   const int c2 = 2 * lane;
+  const unsigned long long below = (1ull << lane) - 1ull;   // the lanes before this one
+  constexpr int kMine = kBucketClusters / kSumWaves;         // clusters per wave
 
   for (int64_t ch = ch0; ch < ch1; ++ch) {
     const int64_t base = s0 + ch * kSumChunk;
     const int64_t left = s1 - base;
     const int n_here = left < kSumChunk ? (int)left : kSumChunk;
-    const int P = pow2_at_least(n_here, 2 * kSumThreads);
     __syncthreads();  // previous chunk fully consumed (and the zeroing above finished)
-    for (int p = threadIdx.x; p < P; p += kSumThreads) {
-      unsigned key = kNoKey;
-      if (p < n_here) {
-        const RowCode rc = perm[base + p];
-        rowbuf[p] = rc.row;
-        key = ((unsigned)(rc.code - (int32_t)c0) << 12) | (unsigned)p;
-      }
-      keybuf[p] = key;
+    for (int p = threadIdx.x; p < n_here; p += kSumThreads) {
+      const RowCode rc = perm[base + p];
+      rowbuf[p] = rc.row;
+      code5[p] = (unsigned char)(rc.code - (int32_t)c0);
     }
-    bitonic_sort_lds<kSumThreads>(keybuf, P);  // by (cluster, position): row order kept
-    if (threadIdx.x <= kBucketClusters)
-      bound[threadIdx.x] = lower_bound_lds(keybuf, n_here, (unsigned)threadIdx.x << 12);
     __syncthreads();
-    // wave w owns the clusters lc with lc % kSumWaves == w
-    for (int lc = wave; lc < kBucketClusters; lc += kSumWaves) {
-      const int lo = bound[lc], hi = bound[lc + 1];
+    // rows per cluster of this wave
+    int n_of[kMine];
+#pragma unroll
+    for (int q = 0; q < kMine; ++q) n_of[q] = 0;
+    for (int p0 = 0; p0 < n_here; p0 += 64) {
+      const int mine = p0 + lane < n_here ? (int)code5[p0 + lane] : -1;
+#pragma unroll
+      for (int q = 0; q < kMine; ++q)
+        n_of[q] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(mine == wave + q * kSumWaves));
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < kMine; ++q) ccount[wave + q * kSumWaves] = n_of[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < kBucketClusters) {
+      int at = 0;
+      for (int u = 0; u < (int)threadIdx.x; ++u) at += ccount[u];
+      cstart[threadIdx.x] = at;
+    }
+    __syncthreads();
+    // positions of each cluster's rows, in row order
+    int fill[kMine];
+#pragma unroll
+    for (int q = 0; q < kMine; ++q) fill[q] = cstart[wave + q * kSumWaves];
+    for (int p0 = 0; p0 < n_here; p0 += 64) {
+      const int mine = p0 + lane < n_here ? (int)code5[p0 + lane] : -1;
+#pragma unroll
+      for (int q = 0; q < kMine; ++q) {
+        const bool hit = mine == wave + q * kSumWaves;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) list[fill[q] + __builtin_popcountll(m & below)] = (unsigned short)(p0 + lane);
+        fill[q] += __builtin_popcountll(m);
+      }
+    }
+    // (the stretches of this wave's clusters were written by this wave: no barrier, the
+    // hardware keeps a wave's LDS accesses in order)
+#pragma unroll 1
+    for (int q = 0; q < kMine; ++q) {
+      const int lc = wave + q * kSumWaves;
+      const int lo = cstart[lc], hi = lo + ccount[lc];
       if (lo == hi) continue;
       double a0 = 0.0, a1 = 0.0;
       // Every load below is unconditional (the tail re-reads the run's last row, lanes past the
@@ -244,7 +290,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cent_sums(
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           const int pp = p + u < hi ? p + u : hi - 1;
-          rows[u] = rowbuf[keybuf[pp] & 4095u];
+          rows[u] = rowbuf[list[pp]];
         }
         float v0[kRowsInFlight], v1[kRowsInFlight];
 #pragma unroll
