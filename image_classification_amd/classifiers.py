@@ -94,6 +94,12 @@ class KNNScikit(object):
                              "n_samples_fit = %d, n_samples = %d"
                              % (neighbors, n_fit, np.asarray(features).shape[0]))
         features = np.asarray(features)
+        if features.ndim == 1 and features.shape[0] == self._fit_X.shape[1]:
+            # one sample given as a vector: the logo flow hands the histogram of its one image to
+            # this step that way (vision/logo_recognition/matching_flow.py:37-38, then
+            # `x[0].tolist()` on the result), which the scikit-learn of the reference's time took
+            # as a single row; later versions refuse it
+            features = features[None, :]
         if features.ndim != 2 or features.shape[1] != self._fit_X.shape[1]:
             raise ValueError("X has %s features, but KNNScikit is expecting %d features as input."
                              % (features.shape[1:] or "?", self._fit_X.shape[1]))

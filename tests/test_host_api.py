@@ -14,6 +14,7 @@ import pytest
 import oracle
 from image_classification_amd import (BagOfWords, ImageDesc, KNNScikit, RobustMatcher, Vocabulary,
                                       compute_vocab_features, kmeans2, kmeans_assign, vq)
+from image_classification_amd.synthetic import sift_like
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REL = 1e-4
@@ -548,7 +549,7 @@ def test_knn_scikit_rejects_what_sklearn_rejects(backend):
         (rng.random((4, 6)), 13),           # more neighbours than fitted rows
         (rng.random((4, 6)), 0),            # no neighbours
         (rng.random((4, 5)), 2),            # feature mismatch
-        (rng.random(6), 2),                 # 1-D query
+        (rng.random(5), 2),                 # 1-D query of the wrong length
     ]
     for feats, k in bad_calls:
         with pytest.raises(Exception) as theirs:
@@ -561,6 +562,81 @@ def test_knn_scikit_rejects_what_sklearn_rejects(backend):
     d_ref, i_ref = ref.kneighbors(fit_x[:5], n_neighbors=3)
     d, i = knn.get_neighbors(fit_x[:5], 3)
     assert np.array_equal(i, i_ref) and np.allclose(d, d_ref, atol=1e-6)
+    # one sample as a vector is one row, as for the scikit-learn of the reference's time: the
+    # logo flow calls this step with the histogram of its one image
+    # (vision/logo_recognition/matching_flow.py:37-38)
+    one = knn.get_neighbors(fit_x[3], 3, dist=False)
+    assert one.shape == (1, 3) and np.array_equal(one, i_ref[3:4])
+
+
+def test_logo_matching_flow_wiring(backend):
+    """The five activities of the reference's logo-matching flow, connected as
+    vision/logo_recognition/matching_flow.py:21-48 connects them (the same lambdas between the
+    steps), on this package's objects: feat_ext -> knn -> acquire_near_logos -> matching ->
+    predict.  A query box that contains a logo must come out with that logo's label, clutter with
+    -1."""
+    rng = np.random.default_rng(77)
+    vocab = sift_like(64, seed=900).astype(np.float64)
+    n_logos, per = 6, 150
+    store = {}
+
+    class FeatExt(object):                       # image "paths" are keys of `store`
+        def extract(self, image_list):
+            return [store[p] for p in image_list]
+
+    hom = np.array([[0.9, 0.08, 30.0], [-0.05, 1.1, 12.0], [1e-4, -5e-5, 1.0]])
+    for n in range(n_logos):
+        store["logo%d" % n] = (rng.random((per, 2)) * 300, sift_like(per, seed=910 + n, n_modes=per))
+    # a box with logo 2 inside (its descriptors with a little noise, its keypoints moved by one
+    # homography) among clutter, and a box of clutter only
+    kp2, d2 = store["logo2"]
+    pick = rng.permutation(per)[:110]
+    moved = np.c_[kp2[pick], np.ones(110)] @ hom.T
+    clutter = sift_like(70, seed=990, n_modes=70)
+    store["box_with_logo2"] = (
+        np.r_[moved[:, :2] / moved[:, 2:] + rng.normal(0, 0.2, (110, 2)), rng.random((70, 2)) * 300],
+        np.r_[d2[pick] + rng.normal(0, 1.5, (110, 128)).astype(np.float32), clutter])
+    store["box_of_clutter"] = (rng.random((160, 2)) * 300, sift_like(160, seed=991, n_modes=160))
+
+    class Logo(object):
+        pass
+
+    class LogoModelStandIn(object):              # vision/logo_recognition/model.py:54-57
+        k_neighbors = 3
+
+        def get_image_descs_and_target_label_ids(self, logo_ids):
+            return ([self.training_logos[n].image_desc for n in logo_ids],
+                    [self.training_logos[n].target_label_id for n in logo_ids])
+
+    lm = LogoModelStandIn()
+    lm.bow = BagOfWords(FeatExt(), vocab=vocab, backend=backend)
+    # KnnTrainer.train (vision/logo_recognition/knn_training.py:34-60)
+    image_descs, logo_hists = lm.bow.extract(["logo%d" % n for n in range(n_logos)])
+    lm.training_logos = []
+    for n, (idesc, h) in enumerate(zip(image_descs, logo_hists)):
+        logo = Logo()
+        logo.image_desc, logo.feature, logo.target_label_id = idesc, h, 1000 + n
+        lm.training_logos.append(logo)
+    # (metric: the pipeline's configured default, vision/logo_recognition/training.py:41,:99-100)
+    lm.knn = KNNScikit(neighbors=3, metric="manhattan", weights="distance", backend=backend)
+    lm.knn.train(logo_hists, list(range(n_logos)))
+    rm = RobustMatcher(10, 8, ransac_th=3, accept_th=0.3, ransac_algorithm=8, ransac_max_iter=100,
+                       ransac_prob=0.95, inlier_r=0.5, backend=backend)
+
+    def run_flow(ip_data):
+        out = lm.bow.extract([ip_data])                                   # feat_ext
+        image_desc, hist = out[0][0], out[1][0]
+        near = lm.knn.get_neighbors(hist, lm.k_neighbors, dist=False)     # knn
+        near_logo_ids = near[0].tolist()
+        near_descs, target_label_ids = lm.get_image_descs_and_target_label_ids(near_logo_ids)
+        scores = rm.match(image_desc, near_descs)                         # matching
+        return rm.predict(scores, target_label_ids), near_logo_ids, scores
+
+    np.random.seed(3)
+    label, near_ids, scores = run_flow("box_with_logo2")
+    assert 2 in near_ids and label == 1002, (near_ids, scores)
+    label, _near, scores = run_flow("box_of_clutter")
+    assert label == -1, scores
 
 
 def test_face_signature_width_is_served_and_wider_rows_are_refused(backend):
