@@ -242,6 +242,25 @@ class RobustMatcher(object):
         homography = H[0].cpu().numpy() if int(n_inl[0]) > 0 else None
         return homography, mask.cpu().numpy().reshape(-1, 1)
 
+    def inlier_pairs(self):
+        """Debug mode, after `match`: per candidate a float array [m, 4] of the inlier matches as
+        (x_query, y_query, x_candidate, y_candidate) -- what the reference's `draw_matches`
+        (model/robust_matching.py:98-155) draws as circles joined by lines.  That method is image
+        I/O through OpenCV and is not part of this package; it reads `query_kpts`, `imgs_kpts` and
+        `mask_list`, which `match` fills here under the same names and shapes."""
+        assert self.debug is True, "You need to be in debug mode"
+        for inst in ["query_kpts", "imgs_kpts", "mask_list"]:
+            assert hasattr(self, inst), "You need to run match function first"
+        out = []
+        for q, im, mask in zip(self.query_kpts, self.imgs_kpts, self.mask_list):
+            if len(mask) == 0:
+                out.append(np.empty((0, 4), dtype=np.float64))
+                continue
+            keep = np.asarray(mask).reshape(-1) == 1
+            out.append(np.concatenate([np.asarray(q, dtype=np.float64)[keep],
+                                       np.asarray(im, dtype=np.float64)[keep]], axis=1))
+        return out
+
     def predict(self, scores, labels):
         """Label of the best score if it reaches `accept_th`, else -1."""
         assert len(scores) == len(labels), "Labels and scores have different size"

@@ -635,6 +635,16 @@ def test_logo_matching_flow_wiring(backend):
     np.random.seed(3)
     label, near_ids, scores = run_flow("box_with_logo2")
     assert 2 in near_ids and label == 1002, (near_ids, scores)
+    # debug mode keeps what the reference's draw_matches reads (drawing_matches.py:43-45)
+    dbg = RobustMatcher(10, 8, ransac_th=3, debug=True, backend=backend)
+    idesc = lm.bow.extract(["box_with_logo2"])[0][0]
+    cands = [lm.training_logos[n].image_desc for n in (2, 4)]
+    dbg_scores = dbg.match(idesc, cands)
+    pairs = dbg.inlier_pairs()
+    assert len(pairs) == 2 and pairs[0].shape[1] == 4
+    assert pairs[0].shape[0] == int(round(dbg_scores[0] * len(dbg.query_kpts[0]))) >= 60
+    moved_back = np.c_[pairs[0][:, 2:], np.ones(len(pairs[0]))] @ hom.T
+    assert np.abs(moved_back[:, :2] / moved_back[:, 2:] - pairs[0][:, :2]).max() < 3.0
     label, _near, scores = run_flow("box_of_clutter")
     assert label == -1, scores
 
