@@ -82,6 +82,41 @@ class KNNScikit(object):
             self._cb = self._b().codebook(features)
             self._is_trained = True
 
+    def train_and_test(self, features, labels):
+        """model/classifiers.py:49-51"""
+        self.train(features, labels)
+        return self.test(features)
+
+    # The reference keeps a fitted index as a pickle of the object (model/classifiers.py:53-63;
+    # vision/logo_recognition/model.py:23 loads the model directory's `knn` file with it).  Same
+    # method names here, but the file is a numpy archive of the fitted rows, the labels and the
+    # constructor arguments -- written under exactly the name given -- and nothing is unpickled.
+    def save_to_file(self, file_name):
+        if not self._is_trained:
+            raise RuntimeError("This KNNScikit instance is not fitted yet.")
+        import json
+        metric = self.metric.__name__ if callable(self.metric) else str(self.metric)
+        kwargs = {k: v for k, v in self.distance_kwargs.items()
+                  if isinstance(v, (int, float, str, bool)) or v is None}
+        with open(file_name, "wb") as f:
+            np.savez(f, fit_x=np.asarray(self._fit_X), labels=np.asarray(self._labels),
+                     neighbors=np.int64(self.n_neighbors), metric=np.str_(metric),
+                     weights=np.str_(self.weights), kwargs=np.str_(json.dumps(kwargs)))
+
+    @classmethod
+    def load_from_file(cls, file_name, backend=None):
+        import json
+        with open(file_name, "rb") as f:
+            data = np.load(f, allow_pickle=False)
+            metric = str(data["metric"])
+            if metric in ("intersection", "chisqr"):
+                metric = getattr(_clustering, metric)
+            kwargs = json.loads(str(data["kwargs"])) if "kwargs" in data.files else {}
+            index = cls(neighbors=int(data["neighbors"]), metric=metric,
+                        weights=str(data["weights"]), backend=backend, **kwargs)
+            index.train(data["fit_x"], list(data["labels"]))
+        return index
+
     def get_neighbors(self, features, neighbors, dist=True):
         if not self._is_trained:
             raise RuntimeError("This KNNScikit instance is not fitted yet.")

@@ -30,19 +30,14 @@ def fit_shortlist_index(bow, paths, labels, neighbors=3, metric=intersection, we
 
 
 def save_shortlist_index(index, path):
-    """Rows and labels of a fitted index as one .npz (metric and weights by name)."""
-    metric = index.metric.__name__ if callable(index.metric) else str(index.metric)
-    np.savez(path, fit_x=np.asarray(index._fit_X), labels=np.asarray(index._labels),
-             neighbors=np.int64(index.n_neighbors), metric=np.str_(metric),
-             weights=np.str_(index.weights))
+    """Rows, labels and constructor arguments of a fitted index as one numpy archive
+    (`KNNScikit.save_to_file`; the archive is written under exactly `path`)."""
+    index.save_to_file(path)
 
 
 def load_shortlist_index(path, backend=None):
-    from . import clustering
-    data = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
-    metric = str(data["metric"])
-    metric = getattr(clustering, metric) if metric in ("intersection", "chisqr") else metric
-    index = KNNScikit(neighbors=int(data["neighbors"]), metric=metric,
-                      weights=str(data["weights"]), backend=backend)
-    index.train(data["fit_x"], list(data["labels"]))
-    return index
+    import os
+    path = str(path)
+    if not os.path.exists(path) and os.path.exists(path + ".npz"):
+        path += ".npz"           # archives written by numpy.savez under a name without suffix
+    return KNNScikit.load_from_file(path, backend=backend)

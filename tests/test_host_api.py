@@ -263,6 +263,20 @@ def test_knn_scikit_intersection_metric_and_shortlist_index(backend, tmp_path):
     # on disk: rows, labels, metric by name -- no pickle
     save_shortlist_index(index, str(tmp_path / "knn"))
     again = load_shortlist_index(str(tmp_path / "knn"), backend=backend)
+    # the reference's own method names (model/classifiers.py:53-63; LogoModel loads the model
+    # directory's file `knn` with them, vision/logo_recognition/model.py:23): the file is written
+    # under exactly that name and holds arrays, no pickle
+    assert os.path.isfile(str(tmp_path / "knn"))
+    index.save_to_file(str(tmp_path / "knn2"))
+    via_method = KNNScikit.load_from_file(str(tmp_path / "knn2"), backend=backend)
+    assert np.array_equal(via_method.get_neighbors(hists[:4], 3, dist=False),
+                          index.get_neighbors(hists[:4], 3, dist=False))
+    assert via_method.metric is index.metric and via_method.weights == index.weights
+    with pytest.raises(RuntimeError):
+        KNNScikit(3, backend=backend).save_to_file(str(tmp_path / "unfitted"))
+    fresh = KNNScikit(1, metric="manhattan", backend=backend)
+    labs = [int(l) for l in g["labels"]]
+    assert list(fresh.train_and_test(hists, labs)) == labs      # every row is its own neighbour
     assert again.metric is intersection and again.n_neighbors == 3
     assert np.array_equal(again.get_neighbors(g["q"], 3, dist=False), g["intersection_ind"])
     assert list(again.test(g["q"])) == list(index.test(g["q"]))
