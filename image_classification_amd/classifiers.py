@@ -82,6 +82,25 @@ class KNNScikit(object):
             self._cb = self._b().codebook(features)
             self._is_trained = True
 
+    # Evaluation helpers of the reference (model/classifiers.py:199-215) over `DataBag`-like
+    # objects with `.feats` and `.labs`; accuracy is the fraction of equal labels, as
+    # sklearn.metrics.accuracy_score and KNeighborsClassifier.score compute it.
+    @classmethod
+    def score_proba(cls, train_bag, test_bag, neg_bag, min_prob_diff=0.4, **kwargs):
+        knn = cls(**kwargs)
+        knn.train(train_bag.feats, train_bag.labs)
+        y_test_pred = knn.test_probability(test_bag.feats, min_prob_diff)
+        test_score = float(np.mean(np.asarray(test_bag.labs) == np.asarray(y_test_pred)))
+        y_neg_pred = knn.test_probability(neg_bag.feats, min_prob_diff)
+        neg_score = 1 - float(np.mean(np.asarray(neg_bag.labs) == np.asarray(y_neg_pred)))
+        return test_score, neg_score
+
+    @classmethod
+    def score(cls, train_bag, test_bag, **kwargs):
+        knn = cls(**kwargs)
+        knn.train(train_bag.feats, train_bag.labs)
+        return float(np.mean(knn.test(test_bag.feats) == np.asarray(test_bag.labs)))
+
     def train_and_test(self, features, labels):
         """model/classifiers.py:49-51"""
         self.train(features, labels)

@@ -169,21 +169,34 @@ class BagOfWords(object):
         return got[1]
 
     # -- descriptors -----------------------------------------------------------------------------
+    # The reference's helper names (model/features.py:1141-1190), kept because subclasses hook
+    # into them; `train` / `extract` go through them.
+    def _feature_extract(self, image_list):
+        return [ImageDesc(*r) for r in self.feat_ext.extract(image_list)]
+
+    def _merge_descs_to_feats(self, image_descs):
+        return np.concatenate([d.descriptors for d in image_descs if d.descriptors is not None])
+
+    def _learn_projection(self, all_feats):
+        self.projection.train(all_feats)
+
+    def _project(self, image_descs):
+        return [ImageDesc(d.cv_keypoints,
+                          None if d.descriptors is None else self.projection.project(d.descriptors))
+                for d in image_descs]
+
     def _describe(self, image_list, fit_projection=False):
         """Extractor output as ImageDescs, projected when a projection is configured (fitted on
         all descriptors of the call first when `fit_projection`)."""
-        descs = [ImageDesc(*r) for r in self.feat_ext.extract(image_list)]
+        descs = self._feature_extract(image_list)
         if not self.projection:
             return descs
         if fit_projection:
-            self.projection.train(self._stack(descs))
-        return [ImageDesc(d.cv_keypoints,
-                          None if d.descriptors is None else self.projection.project(d.descriptors))
-                for d in descs]
+            self._learn_projection(self._merge_descs_to_feats(descs))
+        return self._project(descs)
 
-    @staticmethod
-    def _stack(image_descs):
-        return np.concatenate([d.descriptors for d in image_descs if d.descriptors is not None])
+    def _stack(self, image_descs):
+        return self._merge_descs_to_feats(image_descs)
 
     def _learn_vocab(self, all_feats):
         self._vocab_trainer = Vocabulary(self.vocabsize, backend=getattr(self, "_backend", None))

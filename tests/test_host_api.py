@@ -277,6 +277,19 @@ def test_knn_scikit_intersection_metric_and_shortlist_index(backend, tmp_path):
     fresh = KNNScikit(1, metric="manhattan", backend=backend)
     labs = [int(l) for l in g["labels"]]
     assert list(fresh.train_and_test(hists, labs)) == labs      # every row is its own neighbour
+
+    # the evaluation helpers over DataBag-like objects (model/classifiers.py:199-215)
+    class Bag(object):
+        def __init__(self, feats, labs):
+            self.feats, self.labs = feats, labs
+
+    train_bag = Bag(hists, labs)
+    assert KNNScikit.score(train_bag, Bag(hists[:5], labs[:5]), neighbors=1, metric="manhattan",
+                           backend=backend) == 1.0
+    test_score, neg_score = KNNScikit.score_proba(
+        train_bag, Bag(hists[:5], labs[:5]), Bag(hists[:5], [-1] * 5), min_prob_diff=0.0,
+        neighbors=1, metric="manhattan", backend=backend)
+    assert test_score == 1.0 and neg_score == 1.0
     assert again.metric is intersection and again.n_neighbors == 3
     assert np.array_equal(again.get_neighbors(g["q"], 3, dist=False), g["intersection_ind"])
     assert list(again.test(g["q"])) == list(index.test(g["q"]))
