@@ -16,10 +16,10 @@ from .scene_functions import (compute_spatial_features, compute_spatial_features
                               compute_vocab_features)
 from .classifiers import KNNScikit
 from .robust_matching import RobustMatcher
-from .shortlist import fit_shortlist_index
+from .shortlist import KnnTrainer, fit_shortlist_index
 
 __all__ = ["ImageDesc", "vq", "kmeans2", "kmeans_assign", "kmeans_fit", "BagOfWords",
            "SpatialBagOfWords", "Vocabulary", "compute_vocab_features", "compute_spatial_features",
-           "compute_spatial_features_from_xml", "KNNScikit", "fit_shortlist_index", "RobustMatcher",
+           "compute_spatial_features_from_xml", "KNNScikit", "KnnTrainer", "fit_shortlist_index", "RobustMatcher",
            "intersection", "chisqr"]
 __version__ = "0.1.0"
