@@ -83,11 +83,14 @@ class HipBackend(object):
         that takes histogram blocks down while later rows are still being searched."""
         total = sum(p.shape[0] for p in parts)
         if total <= ops.HOST_CHUNK_ROWS * 2:
+            # (the offsets go up first: a copy from pageable memory blocks the caller until
+            # everything enqueued before it has run, which would otherwise include the search)
+            off = self.i64(offsets)
             if parts:
                 codes, _ = self.assign_top1_parts(parts, cb, want_dist=False)
             else:
                 codes = self.i32(np.empty(0, dtype=np.int32))
-            hists = self.hist(codes, self.i64(offsets), k, norm, power)
+            hists = self.hist(codes, off, k, norm, power)
             return codes, self.to_host(hists)
         return ops.quantize_parts_to_host(parts, offsets, cb.c, cb.aux, k, norm, power)
 
