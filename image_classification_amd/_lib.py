@@ -45,6 +45,8 @@ _SIGNATURES = {
     "ic_codebook_aux": [_p, _p, _c_i64, _c_int, _p, _p],
     "ic_debug_flagged": [_p, _p],
     "ic_debug_plan": [_c_i64, _c_i64, _c_int, _c_int, ctypes.POINTER(_c_i64)],
+    "ic_debug_plan_order": [_c_i64, _c_i64, _c_int, _c_int, ctypes.POINTER(ctypes.c_int32), _c_int,
+                            ctypes.POINTER(_c_int)],
     "ic_assign_top1": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
     "ic_assign_top1_static": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p],
     "ic_assign_top1_hint": [_p, _p, _c_i64, _p, _c_i64, _c_int, _p, _p, _p, _p, _p],

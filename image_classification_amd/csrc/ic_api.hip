@@ -515,6 +515,23 @@ int ic_debug_plan(int64_t n, int64_t k, int d, int num_cus, int64_t* out) {
   return IC_OK;
 }
 
+int ic_debug_plan_order(int64_t n, int64_t k, int d, int num_cus, int32_t* order, int cap,
+                        int* count) {
+  if (!count || n < 1 || n >= 0x7fffffffLL || k < 1 || k > 0x7fffffffLL || d < 1 ||
+      d > ic::kMaxWideD || num_cus < 1 || cap < 0 || (cap > 0 && !order))
+    return fail(IC_EINVAL, "ic_debug_plan_order: bad argument");
+  const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
+  ic::AssignPlan p;
+  ic::assign_plan(n, k, num_cus, &p, D);
+  *count = 0;
+  if (!p.tail_ordered) return IC_OK;
+  if (p.tail_wgs > cap) return fail(IC_ELIMIT, "ic_debug_plan_order: %lld entries, room for %d",
+                                    (long long)p.tail_wgs, cap);
+  for (int64_t b = 0; b < p.tail_wgs; ++b) order[b] = p.tail_order[b];
+  *count = (int)p.tail_wgs;
+  return IC_OK;
+}
+
 int ic_assign_top1(void* handle, const float* x, int64_t n, const float* c, int64_t k, int d,
                    const float* c_aux, int32_t* idx, float* dist, void* stream) {
   if (!idx) return fail(IC_EINVAL, "ic_assign_top1: idx is NULL");

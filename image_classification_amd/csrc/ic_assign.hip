@@ -40,8 +40,10 @@
 // differences decides the row; if so the row is flagged and searched again by direct differences
 // over the whole codebook (k_exact_rows).  The direct-difference arithmetic is the same function in
 // both places, so results equal those of the all-direct search (ic_assign_top2_exact) on every row.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "ic_internal.h"
 
@@ -126,6 +128,7 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   p->tail_wgs = tail;
   p->max_pieces = 1;
   p->wide_pieces = 0;
+  p->tail_ordered = 0;
   if (wide && D >= kWidePieceD && forced <= 0) {
     // A workgroup of the wide search reads its 256 rows again for every chunk of 64 codewords,
     // and the rows of all resident workgroups together (0.5 MB x D / 128 ... 1 GB at 2048
@@ -178,6 +181,22 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
       p->tail_wgs = tail * Pa;
       p->max_pieces = (int)Pa;
     }
+  }
+  // runs that begin anywhere in the codebook: hand them to the XCDs by first stage
+  if (!wide && p->tail_span == (int)stages && p->tail_wgs > 8 && p->tail_wgs <= kMaxTailOrder &&
+      stages > 2) {
+    const int nw = (int)p->tail_wgs;
+    std::vector<int> runs((size_t)nw);
+    for (int r = 0; r < nw; ++r) runs[(size_t)r] = r;
+    const int64_t qq = p->tail_quota;
+    std::stable_sort(runs.begin(), runs.end(), [&](int a, int b) {
+      return (a * qq) % stages < (b * qq) % stages;
+    });
+    int next = 0;
+    for (int xcd = 0; xcd < 8; ++xcd)
+      for (int b = 0; b < nw; ++b)
+        if ((p->full_tiles + b) % 8 == xcd) p->tail_order[b] = (uint16_t)runs[(size_t)next++];
+    p->tail_ordered = 1;
   }
 }
 
@@ -558,6 +577,12 @@ __host__ __device__ __forceinline__ int tail_pieces(const TailGeom& t, int64_t t
   return (int)(((tt + 1) * t.stages - 1) / t.quota) - tail_first_run(t, tt) + 1;
 }
 
+// AssignPlan::tail_order as a kernel argument
+struct TailOrder {
+  int on;
+  uint16_t run[kMaxTailOrder];
+};
+
 #ifdef IC_TRACE
 // Timeline instrumentation of the search kernel (tools/wgtrace.py; built as a separate library by
 // `make trace`, never part of libic_hip.so): per workgroup the 100 MHz wall clock at entry, at the
@@ -591,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ aux, int stages_total, int tail_span, int full_tiles,
     int64_t tail_units, int tail_quota, const float* __restrict__ thr, PartBufs pb,
     float* __restrict__ rowband, uint32_t* __restrict__ zero_word,
-    const int32_t* __restrict__ perm) {
+    const int32_t* __restrict__ perm, TailOrder order) {
   static_assert(XT == 1, "one 32-descriptor tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -617,14 +642,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
   if ((int)blockIdx.x >= full_tiles) {
     // (tail_span = stages_total: runs may cross into the next row tile; larger: the runs are
     // aligned to the row tiles and the places behind a tile's last stage are padding)
-    const int64_t u = (int64_t)((int)blockIdx.x - full_tiles) * tail_quota;
+    // which run of the tail this workgroup walks (see AssignPlan::tail_order)
+    const int b = (int)blockIdx.x - full_tiles;
+    const int run = order.on ? (int)order.run[b < kMaxTailOrder ? b : 0] : b;
+    const int64_t u = (int64_t)run * tail_quota;
     const int64_t tt = u / tail_span;
     const int64_t rest = tail_units - u;
     tile = full_tiles + (int)tt;
     st = (int)(u - tt * tail_span);
     left = rest < tail_quota ? (int)rest : tail_quota;
     if (tail_span != stages_total && left > stages_total - st) left = stages_total - st;
-    piece = ((int)blockIdx.x - full_tiles) - (int)(tt * tail_span / tail_quota);
+    piece = run - (int)(tt * tail_span / tail_quota);
   }
   const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
   const int n_rows = (int)N;
@@ -838,9 +866,19 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
       plan.tail_wgs != (tail_tiles * plan.tail_span + plan.tail_quota - 1) / plan.tail_quota)
     return hipErrorInvalidValue;
   if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+  TailOrder order = {};
+  order.on = plan.tail_ordered;
+  if (order.on) {
+    if (plan.tail_wgs > kMaxTailOrder) return hipErrorInvalidValue;
+    for (int64_t b = 0; b < plan.tail_wgs; ++b) {
+      if (plan.tail_order[b] >= plan.tail_wgs) return hipErrorInvalidValue;
+      order.run[b] = plan.tail_order[b];
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
                      (int)stages, plan.tail_span, (int)plan.full_tiles,
-                     tail_tiles * plan.tail_span, plan.tail_quota, thr, pb, rowband, zero_word, perm);
+                     tail_tiles * plan.tail_span, plan.tail_quota, thr, pb, rowband, zero_word, perm,
+                     order);
   return hipGetLastError();
 }
 

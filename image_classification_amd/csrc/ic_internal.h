@@ -21,6 +21,7 @@ static_assert(sizeof(ic_top2_rec) == 16, "ic_top2_rec must be 16 bytes");
 // full_tiles row tiles are scanned over the whole codebook by one workgroup each.  The remaining
 // row tiles' (row tile, stage) pairs form one line, tile after tile, that tail_wgs workgroups
 // walk in runs of tail_quota stages; a row tile's stages then fall into at most max_pieces runs.
+constexpr int kMaxTailOrder = 1024;   // tails of more workgroups are walked in plain order
 struct AssignPlan {
   int waves, stage_k, rows_per_wg;
   int stages;                      // codebook stages
@@ -32,6 +33,13 @@ struct AssignPlan {
   int wide_pieces;                 // rows of 512 columns and more: every row tile is cut into this
                                    // many pieces of tail_quota stages whose workgroups share an
                                    // XCD (0: the line walk above)
+  // Which run of the tail a workgroup of the tail walks (tail_ordered != 0): the runs begin at
+  // codebook stages spread over the whole codebook, and the workgroups of one XCD -- ids that
+  // differ by multiples of 8 -- are handed runs whose first stages follow each other, so that a
+  // stage one of them has fetched into the XCD's L2 is still there when its neighbours ask for
+  // it a few stages later (in plain order the XCD fetched nearly every stage once per workgroup).
+  int tail_ordered;
+  uint16_t tail_order[kMaxTailOrder];
 };
 // D: columns of a row after padding to a multiple of 128 (more than 128: always the 8-wave
 // geometry)

@@ -125,6 +125,11 @@ int ic_debug_flagged(void* handle, uint32_t* count); /* `count` must stay valid 
  * falls into, workgroups of the tail, pieces per row tile of the wide search (0: none), records
  * of the partial buffer.  The CPU tests replay the kernels' index arithmetic against it. */
 int ic_debug_plan(int64_t n, int64_t k, int d, int num_cus, int64_t* out);
+/* The same plan's hand-out of the tail's runs: order[b] = the run that workgroup b of the tail
+ * walks (the runs are dealt to the XCDs by the codebook stage they begin at); *count = entries
+ * written, 0 when the tail is walked in plain order.  Test hook like ic_debug_plan. */
+int ic_debug_plan_order(int64_t n, int64_t k, int d, int num_cus, int32_t* order, int cap,
+                        int* count);
 
 /* Nearest codeword per row: idx[i] = argmin_j ||x_i - c_j|| (lowest j on ties), dist[i] = that
  * Euclidean distance.  Replaces scipy.cluster.vq.vq at model/features.py:1166 and

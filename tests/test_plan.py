@@ -23,7 +23,15 @@ def plan(n, k, d=128, cus=256):
     return dict(zip(FIELDS, (int(v) for v in out)))
 
 
-def walk(p, n):
+def tail_order(n, k, d=128, cus=256):
+    buf = (ctypes.c_int32 * 1024)()
+    cnt = ctypes.c_int(0)
+    rc = _lib.load().ic_debug_plan_order(n, k, d, cus, buf, 1024, ctypes.byref(cnt))
+    assert rc == 0, _lib.last_error()
+    return [int(buf[i]) for i in range(cnt.value)]
+
+
+def walk(p, n, order=None):
     """[(row tile, first stage, stages, piece)] of every workgroup run, as the kernels derive them
     from blockIdx."""
     runs = []
@@ -46,7 +54,10 @@ def walk(p, n):
     for g in range(full):
         runs.append((g, 0, S, 0))
     tail_units = (p["row_tiles"] - full) * span
-    for g in range(p["tail_wgs"]):
+    if order:
+        assert sorted(order) == list(range(p["tail_wgs"])), "the hand-out is not a permutation"
+    for b in range(p["tail_wgs"]):
+        g = order[b] if order else b
         u = g * q
         tt = u // span
         rest = tail_units - u
@@ -73,7 +84,7 @@ def check(n, k, d=128, cus=256):
     assert 0 <= p["full_tiles"] <= p["row_tiles"]
     covered = np.zeros((p["row_tiles"], S), dtype=np.int32)
     pieces = [set() for _ in range(p["row_tiles"])]
-    for tile, st, cnt, piece in walk(p, n):
+    for tile, st, cnt, piece in walk(p, n, tail_order(n, k, d, cus)):
         assert 0 <= tile < p["row_tiles"] and 0 <= st and st + cnt <= S
         covered[tile, st:st + cnt] += 1
         assert piece not in pieces[tile], "two runs write the same records"
@@ -133,6 +144,24 @@ def test_wide_rows_share_an_xcd():
         assert len({g & 7 for g in ids}) == 1
         places = sorted(g >> 3 for g in ids)
         assert places == list(range(places[0], places[0] + P))
+
+
+def test_tail_runs_are_dealt_to_the_xcds_by_first_stage():
+    # BASELINE config 2: 162 row tiles of the last round as 256 runs of 50 stages; the workgroups
+    # of one XCD (ids 8 apart) get runs whose first stages follow each other
+    n, k = 1_000_000, 10_000
+    p = plan(n, k)
+    order = tail_order(n, k)
+    assert len(order) == p["tail_wgs"] == 256 and p["tail_span"] == p["stages"]
+    S, q = p["stages"], p["tail_quota"]
+    last = -1
+    for xcd in range(8):
+        starts = [(order[b] * q) % S for b in range(len(order)) if (p["full_tiles"] + b) % 8 == xcd]
+        assert starts == sorted(starts) and starts[0] >= last
+        assert starts[-1] - starts[0] <= S // 4       # a window of the codebook, not all of it
+        last = starts[-1]
+    # aligned pieces and the wide search keep the plain order
+    assert tail_order(4000, 2_000_000 // 64) == [] and tail_order(100_000, 600, 1937) == []
 
 
 def test_bad_arguments_are_refused():
