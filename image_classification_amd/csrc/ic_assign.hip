@@ -51,6 +51,22 @@ namespace ic {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One 16-byte chunk of a row centred on the codebook mean and scaled by -2: fma(-2, x, 2 m) rounds
+// once, exactly like x - m, and doubling is exact.  Two components per instruction (v_pk_fma_f32);
+// sq gathers the squares, even components in one half and odd ones in the other.
+__device__ __forceinline__ void centre_chunk(const f32x4 x, const f32x4 mu2, float* out, f32x2& sq) {
+  const f32x2 m2 = {-2.0f, -2.0f};
+  const f32x2 a = __builtin_elementwise_fma(m2, x.lo, mu2.lo);
+  const f32x2 b = __builtin_elementwise_fma(m2, x.hi, mu2.hi);
+  sq = __builtin_elementwise_fma(a, a, sq);
+  sq = __builtin_elementwise_fma(b, b, sq);
+  out[0] = a.x;
+  out[1] = a.y;
+  out[2] = b.x;
+  out[3] = b.y;
+}
 
 constexpr int kTileK = 32;                          // codewords per MFMA tile
 constexpr int kRowBytes = kD * 4 + 16;              // 528: one 16-byte pad chunk per codeword row
@@ -98,6 +114,11 @@ constexpr int kSmallCodebook = 8192;   // below this: two 8-wave workgroups per 
 // Rows of kWidePieceD columns and more are cut differently (see k_top2_wide).
 constexpr int kWidePieceD = 512;
 constexpr int kWidePieces = 16;
+// Codebooks that fit in LDS whole are kept there from this many rows on (k_top2_resident); below,
+// loading 132 KB into every CU before the first multiplication costs more than it saves
+// (256 codewords, streamed / resident: 32 000 rows 27 / 31 us, 64 000 and 100 000 equal, 200 000
+// 141 / 123 us, 1 M 536 / 502 us).
+constexpr int64_t kResidentMinRows = 98304;
 
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   const bool wide = D > kD;
@@ -129,6 +150,31 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   p->max_pieces = 1;
   p->wide_pieces = 0;
   p->tail_ordered = 0;
+  p->resident = 0;
+  p->resident_wgs = 0;
+  // IC_AMD_RESIDENT: 0 = never keep the codebook resident, 1 = whenever it fits (tuning aid and
+  // the tests' way to reach that kernel with few rows)
+  static const int resident_mode = [] {
+    const char* v = getenv("IC_AMD_RESIDENT");
+    return v ? atoi(v) : -1;
+  }();
+  if (!wide && k <= kResidentMaxK && forced <= 0 && geom == 0 && resident_mode != 0 &&
+      (resident_mode == 1 || n >= kResidentMinRows)) {
+    p->waves = 16;
+    p->stage_k = 128;
+    p->rows_per_wg = 512;
+    p->stages = (int)((k + 127) / 128);
+    p->row_tiles = (n + 511) / 512;
+    p->full_tiles = p->row_tiles;
+    p->tail_quota = p->stages;
+    p->tail_span = p->stages;
+    p->tail_wgs = 0;
+    p->resident = 1;
+    const int64_t wave_tiles = (n + 31) / 32;
+    const int64_t wgs = (wave_tiles + 3) / 4;     // at least one tile per SIMD
+    p->resident_wgs = (int)(wgs < num_cus ? wgs : num_cus);
+    return;
+  }
   if (wide && D >= kWidePieceD && forced <= 0) {
     // A workgroup of the wide search reads its 256 rows again for every chunk of 64 codewords,
     // and the rows of all resident workgroups together (0.5 MB x D / 128 ... 1 GB at 2048
@@ -714,20 +760,15 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
       int moff = h * 16;
       asm volatile("" : "+v"(moff));
       const f32x4* mp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(mu_lds) + moff);
-      float xn4 = 0.f;
+      f32x2 sq = {0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const f32x4 mu2 = mp[2 * q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = __builtin_fmaf(-2.0f, xv[q][e], mu2[e]);
-          xn4 = __builtin_fmaf(t, t, xn4);
-          xr[0][q * 4 + e] = t;
-        }
+        centre_chunk(xv[q], mp[2 * q], &xr[0][q * 4], sq);
         // one chunk after the other: scheduled freely, the sixteen chunks' values are all alive
         // at once and a few registers spill to scratch memory
         __builtin_amdgcn_sched_barrier(0);
       }
+      float xn4 = sq.x + sq.y;
       xn4 += __shfl_xor(xn4, 32);
       const float xn = 0.25f * xn4;
       // the band's constant part needs R = |x - m|^2 + 2 (x - m).m (what separates the computed
@@ -836,6 +877,201 @@ extern "C" int ic_trace_read(void* host_dst, size_t bytes) {
                                   hipMemcpyDeviceToHost);
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// Codebooks of at most 256 words (k-means hashing tables, small vocabularies): the padded image of
+// the WHOLE codebook is 135 KB and stays in LDS, in the layout of two 128-word stages, for the
+// life of a workgroup.  One workgroup of 16 waves per CU loads it once; after that single barrier
+// every wave is on its own: it takes tiles of 32 rows (tile = it * 16 G + slot, G workgroups),
+// scans the codebook out of LDS, writes its lists and goes on.  There are no stage loads and no
+// barriers inside the walk, so the four waves of a SIMD drift apart and one wave's ranking and
+// row loads fall into the others' multiplications.  The rows of a wave's NEXT tile are loaded
+// during the last codeword tile of the current one: each 16-byte chunk of the row registers is
+// overwritten by the load of the next rows' chunk right behind the four multiplications that
+// read it last, so the loads fly while the rest of the tile multiplies and is ranked.
+// Slots are numbered CU first, then SIMD, then wave within the SIMD (wave w of a workgroup sits
+// on SIMD w % 4), so the tiles of the last, partly filled round spread over all CUs and SIMDs.
+// Every tile of such a scan is one of its first: all candidates are inserted without tests.
+template <bool MODE2>
+__global__ __launch_bounds__(1024, 4) void k_top2_resident(
+    const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
+    const float* __restrict__ aux, const float* __restrict__ thr, PartBufs pb,
+    float* __restrict__ rowband, uint32_t* __restrict__ zero_word) {
+  constexpr int NW = 16, SK = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31;
+  const int h = lane >> 5;
+  const float* __restrict__ cnp = aux + kAuxNorms;
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
+  const int n_rows = (int)N;
+  const int n_tiles = (n_rows + 31) >> 5;          // tiles of 32 rows
+  const int G = (int)gridDim.x;
+  const int stride = NW * G;
+  int wt = (wave >> 2) * (4 * G) + (wave & 3) * G + (int)blockIdx.x;
+
+  float* mu_lds = reinterpret_cast<float*>(smem + 2 * Stage<SK>::kBytes) + wave * kD;
+  const float* __restrict__ mean2 = cnp + (K + kStageK - 1) / kStageK * kStageK;
+  if (lane < 32) glds16(mean2 + lane * 4, reinterpret_cast<char*>(mu_lds));
+  issue_stage<NW, SK>(C, K, cnp, 0, smem, wave, lane);
+  if (K > SK) issue_stage<NW, SK>(C, K, cnp, 1, smem + Stage<SK>::kBytes, wave, lane);
+
+  // rows of a tile, 64 components per lane: raw as loaded, then centred in place
+  float xr[1][64];
+  auto rows_of = [&](int t) {
+    int r = t * 32 + j;
+    r = r < n_rows ? r : n_rows - 1;
+    return reinterpret_cast<const f32x4*>(X + (int64_t)r * kD + h * 4);
+  };
+  {
+    const f32x4* p = rows_of(wt < n_tiles ? wt : n_tiles - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const f32x4 v = p[2 * q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xr[0][q * 4 + e] = v[e];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // The four waves of a SIMD leave the barrier together and would rank, wait for LDS and load
+  // rows at the same moments; they are started up to 10 us apart instead (the matrix pipe is
+  // busy with the earlier ones meanwhile).  Worth 0.3 ... 0.7 points at 1 M rows.  The index is
+  // 0..3 within a SIMD whether the hardware deals waves to SIMDs round-robin or in fours.
+  for (int i = ((wave + (wave >> 2)) & 3) * 16; i > 0; --i) __builtin_amdgcn_s_sleep(8);
+
+  const float cn_max = aux[kAuxCnMax], cr2_max = aux[kAuxCr2Max], mean_norm = aux[kAuxMeanNorm];
+  const int k_tiles = (K + kTileK - 1) / kTileK;
+  for (; wt < n_tiles; wt += stride) {
+    const int row = wt * 32 + j;
+    float c0[1];
+    {
+      int moff = h * 16;
+      asm volatile("" : "+v"(moff));
+      const f32x4* mp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(mu_lds) + moff);
+      f32x2 sq = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x4 raw = {xr[0][q * 4], xr[0][q * 4 + 1], xr[0][q * 4 + 2], xr[0][q * 4 + 3]};
+        centre_chunk(raw, mp[2 * q], &xr[0][q * 4], sq);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float xn4 = sq.x + sq.y;
+      xn4 += __shfl_xor(xn4, 32);
+      const float xn = 0.25f * xn4;
+      const float bound = error_bound(xn, cn_max, cr2_max);
+      const float r_up = xn + 2.000001f * __builtin_amdgcn_sqrtf(xn) * 1.000001f * mean_norm;
+      c0[0] = 2.01f * bound + kBandSlope * r_up;
+    }
+    Top2 best[1];
+    float gate[1];
+    {
+      float start = kNone;
+      if (thr) start = thr[row < n_rows ? row : n_rows - 1];
+      best[0].d1 = start;
+      best[0].d2 = start;
+      best[0].d3 = start;
+      best[0].d4 = start;
+      best[0].i1 = -1;
+      best[0].i2 = -1;
+      best[0].i3 = -1;
+      gate[0] = start;
+    }
+    f32x16 acc[1];
+    auto tile_at = [&](int t) {
+      return smem + (t >> 2) * Stage<SK>::kBytes + (t & 3) * (kTileK * kRowBytes);
+    };
+    auto norms_at = [&](int t) {
+      return smem + (t >> 2) * Stage<SK>::kBytes + Stage<SK>::kTileBytes + (t & 3) * (kTileK * 4);
+    };
+    for (int t = 0; t + 1 < k_tiles; ++t) {
+      compute_tile<1>(tile_at(t), norms_at(t), xr, acc, j, h);
+      tile_epilogue_gated<1, MODE2, true>(acc, best, gate, c0, t, true);
+    }
+    // (a wave without a next tile loads the last rows again: 16 KB out of L2, once)
+    const int nxt = wt + stride;
+    const f32x4* pn = rows_of(nxt < n_tiles ? nxt : n_tiles - 1);
+    if constexpr (MODE2) {
+      // (the longer lists of a top-2 search leave no registers for the overlapped reload below:
+      // the next rows are loaded once this tile's lists are stored)
+      const int t = k_tiles - 1;
+      compute_tile<1>(tile_at(t), norms_at(t), xr, acc, j, h);
+      tile_epilogue_gated<1, MODE2, true>(acc, best, gate, c0, t, true);
+    } else {
+      // the last codeword tile, with the next tile's rows loaded behind the multiplications
+      const int t = k_tiles - 1;
+      const char* tile_base = tile_at(t);
+      const f32x4* cnv = reinterpret_cast<const f32x4*>(norms_at(t) + h * 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 c4 = cnv[g * 2];
+        acc[0][g * 4 + 0] = c4[0];
+        acc[0][g * 4 + 1] = c4[1];
+        acc[0][g * 4 + 2] = c4[2];
+        acc[0][g * 4 + 3] = c4[3];
+      }
+      const f32x4* arow = reinterpret_cast<const f32x4*>(tile_base + j * kRowBytes + h * 16);
+      f32x4 a = arow[0];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        f32x4 an = a;
+        if (q + 1 < 16) an = arow[2 * (q + 1)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], xr[0][q * 4 + e], acc[0], 0, 0, 0);
+        const f32x4 v = pn[2 * q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xr[0][q * 4 + e] = v[e];
+        a = an;
+      }
+      tile_epilogue_gated<1, MODE2, true>(acc, best, gate, c0, t, true);
+    }
+    {
+      const Top2& b = best[0];
+      if (row < n_rows) {
+        ic_top2_rec rec;
+        rec.d1 = b.d1; rec.i1 = decode_candidate(b.i1, b.d1, h, K);
+        rec.d2 = b.d2; rec.i2 = decode_candidate(b.i2, b.d2, h, K);
+        const int64_t slot = (int64_t)h * N + row;   // part_slot of a row tile scanned whole
+        pb.rec[slot] = rec;
+        pb.d3[slot] = b.d3;
+        if constexpr (MODE2) {
+          pb.i3[slot] = decode_candidate(b.i3, b.d3, h, K);
+          pb.d4[slot] = b.d4;
+        }
+        if (rowband && h == 0) rowband[row] = c0[0];
+      }
+    }
+    if constexpr (MODE2) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x4 v = pn[2 * q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xr[0][q * 4 + e] = v[e];
+      }
+    }
+  }
+}
+
+static hipError_t launch_resident(const float* x, int64_t n, const float* c, int64_t k,
+                                  const float* aux, const AssignPlan& plan, bool mode2,
+                                  const float* thr, const PartBufs& pb, float* rowband,
+                                  uint32_t* zero_word, hipStream_t s) {
+  const int64_t wave_tiles = (n + 31) / 32;
+  // the kernel's geometry must be the plan's: k_rescore reads the lists by it
+  if (k < 1 || k > kResidentMaxK || plan.waves != 16 || plan.stage_k != 128 ||
+      plan.rows_per_wg != 512 || plan.stages != (k + 127) / 128 || plan.max_pieces != 1 ||
+      plan.tail_wgs != 0 || plan.full_tiles != plan.row_tiles ||
+      plan.full_tiles * 512 < n || plan.resident_wgs < 1 ||
+      (int64_t)plan.resident_wgs * 4 > wave_tiles + 3)
+    return hipErrorInvalidValue;
+  auto kern = mode2 ? k_top2_resident<true> : k_top2_resident<false>;
+  const int lds = 2 * Stage<128>::kBytes + 16 * kD * 4;
+  hipLaunchKernelGGL(kern, dim3((unsigned)plan.resident_wgs), dim3(1024), lds, s, x, n, c, (int)k,
+                     aux, thr, pb, rowband, zero_word);
+  return hipGetLastError();
+}
 
 // IC_AMD_VARIANT selects the ranking variant for A/B timing in one build: 0 = rank every
 // candidate, anything else (default) = the two-level gate.
@@ -1205,6 +1441,12 @@ hipError_t assign_init() {
   if (e != hipSuccess) return e;
   e = allow_lds_wide();
   if (e != hipSuccess) return e;
+  for (const void* kp : {reinterpret_cast<const void*>(k_top2_resident<false>),
+                         reinterpret_cast<const void*>(k_top2_resident<true>)}) {
+    e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * Stage<128>::kBytes + 16 * kD * 4);
+    if (e != hipSuccess) return e;
+  }
   return exact_init();
 }
 
@@ -1225,6 +1467,10 @@ hipError_t launch_top2_partial(const float* x, int64_t n, const float* c, int64_
     return launch_wide(x, n, c, k, aux, mean, D, plan, mode2, thr, pb, wide_xc, rowband,
                        zero_word, s);
   if (D != kD || mean != aux) return hipErrorInvalidValue;
+  if (plan.resident) {
+    if (perm) return hipErrorInvalidValue;   // such codebooks are never reordered
+    return launch_resident(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, s);
+  }
   if (plan.waves == 8 && plan.stage_k == 64)
     return launch_geometry<8, 64>(x, n, c, k, aux, plan, mode2, thr, pb, rowband, zero_word, perm, s);
   if (plan.waves == 16 && plan.stage_k == 128)

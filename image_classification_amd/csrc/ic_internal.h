@@ -40,7 +40,14 @@ struct AssignPlan {
   // it a few stages later (in plain order the XCD fetched nearly every stage once per workgroup).
   int tail_ordered;
   uint16_t tail_order[kMaxTailOrder];
+  // Codebooks of at most kResidentMaxK words under many rows (resident != 0): the whole codebook
+  // stays in LDS, resident_wgs persistent workgroups of 16 waves (one per CU) are launched, and
+  // every WAVE walks tiles of 32 rows on its own -- no stage loads, no barriers after the first.
+  // The other fields then describe the same search as row tiles of 512 rows scanned whole
+  // (full_tiles = row_tiles, no tail): two lists per row, which is all k_rescore needs to know.
+  int resident, resident_wgs;
 };
+constexpr int64_t kResidentMaxK = 256;
 // D: columns of a row after padding to a multiple of 128 (more than 128: always the 8-wave
 // geometry)
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D = kD);
@@ -72,6 +79,7 @@ inline int64_t aux_mean_offset(int64_t kpad, int D) { return D > kD ? aux_tail_o
 // translates them back as it writes its lists, and every tie is broken by codeword index as before.
 constexpr int64_t kOrderMinK = 256;
 constexpr int64_t kOrderMaxK = 16384;
+static_assert(kResidentMaxK <= kOrderMinK, "codebooks that stay in LDS are searched as stored");
 inline bool aux_ordered(int64_t k, int D) { return D == kD && k > kOrderMinK && k <= kOrderMaxK; }
 inline int64_t aux_perm_offset(int64_t kpad) { return kAuxNorms + kpad + kD; }
 inline int64_t aux_rank_offset(int64_t kpad) { return aux_perm_offset(kpad) + kpad; }

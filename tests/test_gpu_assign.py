@@ -342,6 +342,29 @@ def test_streamed_host_path_equals_device_path():
         vq(bad, c.astype(np.float64))
 
 
+@pytest.mark.parametrize("n,k", [(98_304, 256), (131_089, 255), (200_000, 100), (150_001, 33),
+                                 (120_000, 1), (300_000, 129)])
+def test_codebooks_resident_in_lds_equal_the_direct_search(n, k):
+    """From about 100 000 rows on a codebook of at most 256 words stays in LDS whole and every
+    wave walks 32-row tiles on its own (k_top2_resident): last tiles that are partly filled, waves
+    with one tile more than others, a single stage, one codeword, duplicates (ties go to the
+    lowest index), top-1, top-2 and hinted calls."""
+    rng = np.random.default_rng(n + k)
+    c = sift_like(k, seed=400 + k % 13)
+    if k > 8:
+        dup = rng.integers(0, k, 8)
+        c[dup[:4]] = c[dup[4:]]
+    x = sift_like(n, seed=k % 17)
+    x[:k] = c                                        # exact hits, some of them on duplicates
+    _same_as_direct(x, c)
+    xd, cd = _dev(x), _dev(c)
+    idx, dist = ops.assign_top1(xd, cd)
+    stale = torch.from_numpy(rng.integers(-1, k + 1, size=n).astype(np.int32)).cuda()
+    for hint in (idx, stale):
+        hi, hd = ops.assign_top1(xd, cd, hint=hint)
+        assert torch.equal(hi, idx) and torch.equal(hd, dist)
+
+
 @pytest.mark.parametrize("k", [256, 257, 16384, 16385])
 def test_scan_order_boundaries_equal_the_direct_search(k):
     """Codebooks of 257 ... 16384 words are scanned in ascending order of their distance to the

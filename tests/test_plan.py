@@ -13,11 +13,12 @@ import pytest
 from image_classification_amd import _lib
 
 FIELDS = ("waves", "stage_k", "rows_per_wg", "stages", "tail_span", "row_tiles", "full_tiles",
-          "tail_quota", "max_pieces", "tail_wgs", "wide_pieces", "records")
+          "tail_quota", "max_pieces", "tail_wgs", "wide_pieces", "records", "resident",
+          "resident_wgs")
 
 
 def plan(n, k, d=128, cus=256):
-    out = (ctypes.c_int64 * 12)()
+    out = (ctypes.c_int64 * 14)()
     rc = _lib.load().ic_debug_plan(n, k, d, cus, out)
     assert rc == 0, _lib.last_error()
     return dict(zip(FIELDS, (int(v) for v in out)))
@@ -103,7 +104,32 @@ def check(n, k, d=128, cus=256):
             assert len(got) == ((tt + 1) * span - 1) // q - first + 1
     # record slots (part_slot): lists 0 and 1 for every row, the others only for the tail's rows
     assert p["records"] == 2 * n + (2 * p["max_pieces"] - 2) * (n - split_row0)
+    if p["resident"]:
+        check_resident(p, n, k)
     return p
+
+
+def check_resident(p, n, k):
+    """k_top2_resident: the codebook stays in LDS, every wave walks 32-row tiles on its own
+    (tile = iteration * 16 G + slot, slot = CU first, then SIMD, then wave within the SIMD).  The
+    rest of the plan must read as row tiles scanned whole: two lists per row."""
+    G = p["resident_wgs"]
+    assert k <= 256 and p["waves"] == 16 and p["stage_k"] == 128 and p["max_pieces"] == 1
+    assert p["full_tiles"] == p["row_tiles"] and p["tail_wgs"] == 0 and p["records"] == 2 * n
+    n_tiles = -(-n // 32)
+    assert 1 <= G and 4 * G <= n_tiles + 3        # no workgroup without a tile
+    taken = np.zeros(n_tiles, dtype=np.int32)
+    per_simd = {}
+    for g in range(G):
+        for wave in range(16):
+            wt = (wave >> 2) * (4 * G) + (wave & 3) * G + g
+            while wt < n_tiles:
+                taken[wt] += 1
+                per_simd[(g, wave & 3)] = per_simd.get((g, wave & 3), 0) + 1
+                wt += 16 * G
+    assert (taken == 1).all()
+    loads = list(per_simd.values()) + [0] * (4 * G - len(per_simd))
+    assert max(loads) - min(loads) <= 1, "tiles are not spread evenly over the SIMDs"
 
 
 @pytest.mark.parametrize("n,k,d", [
@@ -164,8 +190,16 @@ def test_tail_runs_are_dealt_to_the_xcds_by_first_stage():
     assert tail_order(4000, 2_000_000 // 64) == [] and tail_order(100_000, 600, 1937) == []
 
 
+def test_small_codebooks_stay_in_lds_from_many_rows_on():
+    assert plan(1_000_000, 256)["resident"] == 1 and plan(1_000_000, 256)["resident_wgs"] == 256
+    assert plan(200_000, 64)["resident"] == 1
+    assert plan(120_000, 256, cus=64)["resident_wgs"] == 64
+    assert plan(20_000, 256)["resident"] == 0          # few rows: streamed as any other codebook
+    assert plan(1_000_000, 257)["resident"] == 0 and plan(1_000_000, 256, d=256)["resident"] == 0
+
+
 def test_bad_arguments_are_refused():
-    out = (ctypes.c_int64 * 12)()
+    out = (ctypes.c_int64 * 14)()
     lib = _lib.load()
     assert lib.ic_debug_plan(0, 10, 128, 256, out) != 0
     assert lib.ic_debug_plan(10, 0, 128, 256, out) != 0

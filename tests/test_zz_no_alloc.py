@@ -53,6 +53,12 @@ def test_static_entry_equals_allocating_entry_on_two_calls_in_a_row():
     assert oracle.check_close(d_s, rd[:, 0]) <= 1e-4
 
 
+def test_static_entry_with_the_codebook_resident_in_lds():
+    # many rows against a small codebook take the kernel that keeps the codebook in LDS
+    i_s, d_s, i_a, d_a, grew = _both(sift_like(150_000, seed=17), sift_like(200, seed=18))
+    assert np.array_equal(i_s, i_a) and np.array_equal(d_s, d_a) and grew == 0
+
+
 def test_static_entry_narrow_rows_use_padded_copies_in_the_scratch():
     x = sift_like(5000, d=64, seed=15)
     c = sift_like(300, d=64, seed=16)
