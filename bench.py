@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the descriptor -> codeword assignment path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload bow|knn|kmeans|video|logo|histknn]
+    python bench.py --gpus N --steps K --warmup W [--workload bow|cfg1|hash|knn|kmeans|video|logo|histknn]
 
 One step = one pass of the hot path over one batch of synthetic descriptors resident in HBM.
 The default workload is BASELINE config 2, "BoW quantisation + per-image L2-normalised histograms:
@@ -67,6 +67,9 @@ WORKLOADS = {
     "cfg1": dict(rows=100_000, k=1000, images=100, norm="l1",
                  name="BASELINE config 1: 100k descriptors x 1k-word codebook x 128-d, nearest "
                       "codeword + per-image L1 histograms (100 images x 1000 descriptors)"),
+    "hash": dict(rows=1_000_000, k=256, images=1000, norm="l1",
+                 name="small codebook (the size of the face index's hashing tables): 1M rows x 256 "
+                      "codewords x 128-d, nearest codeword + occupancy histograms of 1000 batches"),
     "video": dict(rows=4_000_000, k=10_000, images=2000, norm="power_l2",
                   name="BASELINE config 5 (per-GPU share): 2000 frames x 2000 descriptors, 10k words, "
                        "assignment + per-frame power/L2 histograms"),
@@ -302,6 +305,17 @@ def measured_traffic(workload, kernel="k_top2_partial"):
     except Exception:
         return None, None
     return None, None
+
+
+def search_kernel_name(n_rows, k_words, num_cus):
+    """Which of the library's matrix-core search kernels a search of this shape launches (asked
+    of the library's own planner, host arithmetic only)."""
+    import ctypes
+    from image_classification_amd import _lib
+    out = (ctypes.c_int64 * 14)()
+    if _lib.load().ic_debug_plan(int(n_rows), int(k_words), DIM, int(num_cus), out) != 0:
+        return "k_top2_partial"
+    return "k_top2_resident" if out[12] else "k_top2_partial"
 
 
 def adverse_order(cb, x):
@@ -574,7 +588,7 @@ def run_rank(args):
     n_rows, k_words = w["rows"], w["k"]
     flops_per_launch = None
     units_per_step = n_rows  # what `value` counts per rank and step
-    quantising = args.workload in ("bow", "video", "cfg1")
+    quantising = args.workload in ("bow", "video", "cfg1", "hash")
 
     if quantising:
         cb = sift_like_device(k_words, DIM, n_modes=2048, seed=4, device=dev)
@@ -712,8 +726,9 @@ def run_rank(args):
         avg_kernel_s = kern_ms / max(1, launches) / 1e3
         is_pairs = args.workload == "knn"
         is_hist = args.workload == "histknn"
-        traffic, traffic_src = measured_traffic(
-            args.workload, "k_pairdist_few" if is_hist else "k_top2_partial")
+        search_kernel = "k_pairdist_few" if is_hist else search_kernel_name(
+            n_rows, int(flops_per_launch / (2.0 * n_rows * DIM)), props.multi_processor_count)
+        traffic, traffic_src = measured_traffic(args.workload, search_kernel)
         traffic_note = ("rocprofv3 --pmc passes of this workload, committed as %s (not measured "
                         "by this run)" % traffic_src) if traffic_src else None
         if is_hist:
@@ -728,7 +743,7 @@ def run_rank(args):
             roofline = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                         "traffic": traffic, "traffic_source": traffic_note,
-                        "kernel": "k_top2_partial", "avg_kernel_ms": avg_kernel_s * 1e3,
+                        "kernel": search_kernel, "avg_kernel_ms": avg_kernel_s * 1e3,
                         "flops_per_launch": flops_per_launch,
                         "peak_basis": "256 CU x 256 FLOP/clk x 2.4 GHz; this device reports "
                                       "%d CUs%s" % (props.multi_processor_count,
@@ -741,6 +756,7 @@ def run_rank(args):
             metric, unit = ("index histograms compared/sec", "histograms/s")
         parallelism = {"bow": "rows sharded, no collective",
                        "cfg1": "rows sharded, no collective",
+                       "hash": "rows sharded, no collective",
                        "video": "frames sharded, no collective",
                        "logo": "logo images sharded, no collective",
                        "kmeans": "rows sharded, RCCL all-reduce of sums+counts per iteration",
