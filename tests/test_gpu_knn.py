@@ -112,6 +112,26 @@ def test_knn_rows_long_index_few_queries():
         assert idx[0, 0] == 5 and (k < 2 or idx[0, 1] == 30_000)
 
 
+def test_index_larger_than_the_caches_is_streamed_with_the_same_result():
+    # an index of more than 512 MB is read with non-temporal loads; each half of it alone is
+    # below that size and takes the default policy: the distances must be the same bits
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    c = torch.rand((140_000, 1000), device="cuda", generator=g)          # 560 MB
+    c /= c.sum(1, keepdim=True)
+    for m in (1, 2, 3):
+        x = c[1000:1000 + m].clone()
+        whole, wi = ops.knn_rows(x, c, 3, "manhattan")
+        lo, li = ops.knn_rows(x, c[:70_000], 3, "manhattan")
+        hi, hj = ops.knn_rows(x, c[70_000:], 3, "manhattan")
+        both_d = torch.cat([lo, hi], 1)
+        both_i = torch.cat([li, hj + 70_000], 1)
+        order = torch.argsort(both_d, dim=1, stable=True)[:, :3]
+        assert torch.equal(whole, torch.gather(both_d, 1, order))
+        assert torch.equal(wi, torch.gather(both_i, 1, order).int())
+        assert bool((whole[:, 0] == 0).all()) and wi[:, 0].tolist() == list(range(1000, 1000 + m))
+
+
 def test_knn_argument_errors():
     x = _dev(np.zeros((4, 10), np.float32))
     c = _dev(np.zeros((3, 10), np.float32))
