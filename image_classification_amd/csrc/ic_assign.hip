@@ -262,27 +262,66 @@ __device__ __forceinline__ void glds4(const float* src, char* lds_wave_base) {
 // fetches chunk pos % 33 of codeword row pos / 33 (the 33rd chunk of a row is padding and re-reads
 // chunk 0).  Rows past the codebook end re-read the last row; their norm slot holds +inf, so they
 // can never win.
+// The byte offsets a lane's loads of a stage start at (inside the stage's 64 KB or 32 KB of
+// codeword rows) do not depend on the stage: they are worked out once per kernel and kept as
+// 16-bit halves of a few registers, so that issuing a stage costs one vector instruction per
+// load instead of the nine of the division by 33 (vector instructions are MFMA time on this
+// part: 2 % of the 8-wave geometry's stage, 1 % of the 16-wave one's).
+template <int NW, int SK>
+struct StageOffsets {
+  static constexpr int kLoads = (Stage<SK>::kGlds + NW - 1) / NW;   // per wave and stage
+  unsigned packed[(kLoads + 1) / 2];
+  static_assert((SK - 1) * 512 + 31 * 16 < 65536, "offsets are kept in 16 bits");
+};
+__device__ __forceinline__ unsigned stage_offset(int pos, int last) {
+  int r = (pos * 1986) >> 16;  // pos / 33, exact for pos < 8448
+  int c = pos - r * kRowChunks;
+  c = c == kRowChunks - 1 ? 0 : c;
+  r = r < last ? r : last;
+  return (unsigned)r * 512u + (unsigned)c * 16u;
+}
+template <int NW, int SK>
+__device__ __forceinline__ void stage_offsets(StageOffsets<NW, SK>& o, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < StageOffsets<NW, SK>::kLoads; ++i) {
+    int m = wave + NW * i;
+    m = m < Stage<SK>::kGlds ? m : Stage<SK>::kGlds - 1;
+    const unsigned v = stage_offset(m * 64 + lane, SK - 1);
+    if (i & 1) o.packed[i / 2] |= v << 16;
+    else o.packed[i / 2] = v;
+  }
+}
+
 template <int NW, int SK>
 __device__ __forceinline__ void issue_stage(const float* __restrict__ C, int K,
                                             const float* __restrict__ cnp, int st, char* sb,
-                                            int wave, int lane) {
+                                            int wave, int lane, const StageOffsets<NW, SK>& o) {
   // wave-uniform 64-bit base + 32-bit per-lane byte offset (keeps the address math off the VALU)
   const char* base = reinterpret_cast<const char*>(C) + (size_t)st * (SK * kD * 4);
   const int last = K - 1 - st * SK;  // last valid row of this stage (>= 0)
-  // opaque copy: the offsets below are recomputed per call (a few VALU ops) instead of being
-  // hoisted out of the sweep loop and held in registers the MFMA operands need
-  asm volatile("" : "+v"(lane));
+  if (last >= SK - 1) {
 #pragma unroll
-  for (int i = 0; i < (Stage<SK>::kGlds + NW - 1) / NW; ++i) {
-    const int m = wave + NW * i;
-    if (m < Stage<SK>::kGlds) {
-      const int pos = m * 64 + lane;
-      int r = (pos * 1986) >> 16;  // pos / 33, exact for pos < 4224
-      int c = pos - r * kRowChunks;
-      c = c == kRowChunks - 1 ? 0 : c;
-      r = r < last ? r : last;
-      const unsigned voff = (unsigned)r * 512u + (unsigned)c * 16u;
-      glds16(reinterpret_cast<const float*>(base + voff), sb + m * 1024);
+    for (int i = 0; i < StageOffsets<NW, SK>::kLoads; ++i) {
+      const int m = wave + NW * i;
+      if (m < Stage<SK>::kGlds) {
+        // (through asm so that the halves are taken apart here, one instruction each, and not
+        // hoisted out of the sweep into registers of their own)
+        unsigned voff;
+        if (i & 1) asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(voff) : "v"(o.packed[i / 2]));
+        else asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(voff) : "v"(o.packed[i / 2]));
+        glds16(reinterpret_cast<const float*>(base + voff), sb + m * 1024);
+      }
+    }
+  } else {
+    // the codebook ends inside this stage: rows past its end re-read the last one
+    // (opaque copy: these offsets are never hoisted out of the sweep loop)
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i = 0; i < StageOffsets<NW, SK>::kLoads; ++i) {
+      const int m = wave + NW * i;
+      if (m < Stage<SK>::kGlds)
+        glds16(reinterpret_cast<const float*>(base + stage_offset(m * 64 + lane, last)),
+               sb + m * 1024);
     }
   }
 #pragma unroll
@@ -713,8 +752,10 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
 
   int sti = st;            // codebook stage of the next unit to issue
   int to_issue = left;     // units whose stage has not been issued yet
+  StageOffsets<NW, SK> offs;
+  stage_offsets<NW, SK>(offs, wave, lane);
   auto issue_next = [&](char* sb) {
-    issue_stage<NW, SK>(C, K, cnp, sti, sb, wave, lane);
+    issue_stage<NW, SK>(C, K, cnp, sti, sb, wave, lane, offs);
     sti = sti + 1 == stages_total ? 0 : sti + 1;
     --to_issue;
   };
@@ -914,8 +955,12 @@ __global__ __launch_bounds__(1024, 4) void k_top2_resident(
   float* mu_lds = reinterpret_cast<float*>(smem + 2 * Stage<SK>::kBytes) + wave * kD;
   const float* __restrict__ mean2 = cnp + (K + kStageK - 1) / kStageK * kStageK;
   if (lane < 32) glds16(mean2 + lane * 4, reinterpret_cast<char*>(mu_lds));
-  issue_stage<NW, SK>(C, K, cnp, 0, smem, wave, lane);
-  if (K > SK) issue_stage<NW, SK>(C, K, cnp, 1, smem + Stage<SK>::kBytes, wave, lane);
+  {
+    StageOffsets<NW, SK> offs;
+    stage_offsets<NW, SK>(offs, wave, lane);
+    issue_stage<NW, SK>(C, K, cnp, 0, smem, wave, lane, offs);
+    if (K > SK) issue_stage<NW, SK>(C, K, cnp, 1, smem + Stage<SK>::kBytes, wave, lane, offs);
+  }
 
   // rows of a tile, 64 components per lane: raw as loaded, then centred in place
   float xr[1][64];
