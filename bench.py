@@ -312,7 +312,7 @@ def search_kernel_name(n_rows, k_words, num_cus):
     of the library's own planner, host arithmetic only)."""
     import ctypes
     from image_classification_amd import _lib
-    out = (ctypes.c_int64 * 14)()
+    out = (ctypes.c_int64 * 16)()
     if _lib.load().ic_debug_plan(int(n_rows), int(k_words), DIM, int(num_cus), out) != 0:
         return "k_top2_partial"
     return "k_top2_resident" if out[12] else "k_top2_partial"

@@ -508,10 +508,11 @@ int ic_debug_plan(int64_t n, int64_t k, int d, int num_cus, int64_t* out) {
   const int D = (d + ic::kD - 1) / ic::kD * ic::kD;
   ic::AssignPlan p;
   ic::assign_plan(n, k, num_cus, &p, D);
-  const int64_t v[14] = {p.waves, p.stage_k, p.rows_per_wg, p.stages, p.tail_span, p.row_tiles,
+  const int64_t v[15] = {p.waves, p.stage_k, p.rows_per_wg, p.stages, p.tail_span, p.row_tiles,
                          p.full_tiles, p.tail_quota, p.max_pieces, p.tail_wgs, p.wide_pieces,
-                         ic::assign_part_records(p, n), p.resident, p.resident_wgs};
-  for (int i = 0; i < 14; ++i) out[i] = v[i];
+                         ic::assign_part_records(p, n), p.resident, p.resident_wgs,
+                         p.tail_long < p.tail_wgs ? p.tail_long : p.tail_wgs};
+  for (int i = 0; i < 15; ++i) out[i] = v[i];
   return IC_OK;
 }
 

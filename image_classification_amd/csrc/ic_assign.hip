@@ -120,6 +120,32 @@ constexpr int kWidePieces = 16;
 // 141 / 123 us, 1 M 536 / 502 us).
 constexpr int64_t kResidentMinRows = 98304;
 
+// The tail of the grid: tail row tile tt (counted from the first row tile of the tail) owns the
+// units [tt S, (tt + 1) S) of the line of (row tile, stage) pairs; run g of the tail owns q units
+// when g < n_long and q - 1 otherwise, one run after the other.  The pieces of a row tile are
+// the runs its units fall into, numbered from the first such run.
+struct TailGeom {
+  int stages;        // S: units a row tile takes in the line (AssignPlan::tail_span)
+  int quota;         // q
+  int rows_per_wg;
+  int64_t n_long;    // AssignPlan::tail_long
+};
+__host__ __device__ __forceinline__ int64_t tail_run_start(const TailGeom& t, int64_t run) {
+  return run * t.quota - (run > t.n_long ? run - t.n_long : 0);
+}
+// the run unit u belongs to
+__host__ __device__ __forceinline__ int64_t tail_run_of(const TailGeom& t, int64_t u) {
+  const int64_t long_units = t.n_long * t.quota;
+  if (u < long_units || t.quota < 2) return u / t.quota;
+  return t.n_long + (u - long_units) / (t.quota - 1);
+}
+__host__ __device__ __forceinline__ int tail_first_run(const TailGeom& t, int64_t tt) {
+  return (int)tail_run_of(t, tt * t.stages);
+}
+__host__ __device__ __forceinline__ int tail_pieces(const TailGeom& t, int64_t tt) {
+  return (int)tail_run_of(t, (tt + 1) * t.stages - 1) - tail_first_run(t, tt) + 1;
+}
+
 void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   const bool wide = D > kD;
   // IC_AMD_GEOMETRY forces a shape (1 = two 8-wave workgroups per CU, 2 = one of 16; tuning aid)
@@ -147,6 +173,7 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   p->tail_quota = (int)stages;
   p->tail_span = (int)stages;
   p->tail_wgs = tail;
+  p->tail_long = 0x7fffffff;
   p->max_pieces = 1;
   p->wide_pieces = 0;
   p->tail_ordered = 0;
@@ -228,20 +255,36 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
       p->max_pieces = (int)Pa;
     }
   }
+  // Runs of two lengths (see AssignPlan::tail_long): q stages for the first n_long runs, q - 1
+  // for the others, one run per slot.
+  if (forced <= 0 && !wide && p->tail_span == (int)stages && q >= 3 && units > (q - 1) * slots &&
+      units < q * slots) {
+    p->tail_long = units - (q - 1) * slots;
+    p->tail_wgs = slots;
+    const int64_t most = (stages - 1) / (q - 1) + 2;
+    p->max_pieces = (int)(most < stages ? most : stages);
+  }
   // runs that begin anywhere in the codebook: hand them to the XCDs by first stage
   if (!wide && p->tail_span == (int)stages && p->tail_wgs > 8 && p->tail_wgs <= kMaxTailOrder &&
       stages > 2) {
     const int nw = (int)p->tail_wgs;
     std::vector<int> runs((size_t)nw);
     for (int r = 0; r < nw; ++r) runs[(size_t)r] = r;
-    const int64_t qq = p->tail_quota;
+    const TailGeom geom{p->tail_span, p->tail_quota, p->rows_per_wg, p->tail_long};
     std::stable_sort(runs.begin(), runs.end(), [&](int a, int b) {
-      return (a * qq) % stages < (b * qq) % stages;
+      return tail_run_start(geom, a) % stages < tail_run_start(geom, b) % stages;
     });
+    // an XCD gets a window of consecutive first stages; inside the window the long runs take
+    // the XCD's lowest workgroup ids, so that a CU's two workgroups are not both long ones
     int next = 0;
-    for (int xcd = 0; xcd < 8; ++xcd)
+    for (int xcd = 0; xcd < 8; ++xcd) {
+      int mine = 0;
+      for (int b = 0; b < nw; ++b) mine += (p->full_tiles + b) % 8 == xcd;
+      std::stable_partition(runs.begin() + next, runs.begin() + next + mine,
+                            [&](int r) { return r < p->tail_long; });
       for (int b = 0; b < nw; ++b)
         if ((p->full_tiles + b) % 8 == xcd) p->tail_order[b] = (uint16_t)runs[(size_t)next++];
+    }
     p->tail_ordered = 1;
   }
 }
@@ -646,22 +689,6 @@ __device__ __forceinline__ int64_t part_slot(int l, int64_t r, int64_t N, int64_
   return l < 2 ? (int64_t)l * N + r : 2 * N + (int64_t)(l - 2) * (N - split_row0) + (r - split_row0);
 }
 
-// The tail of the grid: tail row tile tt (counted from the first row tile of the tail) owns the
-// units [tt S, (tt + 1) S) of the line of (row tile, stage) pairs, workgroup g of the tail the
-// units [g q, (g + 1) q).  The pieces of a row tile are the runs its units fall into, numbered
-// from the first such run.
-struct TailGeom {
-  int stages;        // S: units a row tile takes in the line (AssignPlan::tail_span)
-  int quota;         // q
-  int rows_per_wg;
-};
-__host__ __device__ __forceinline__ int tail_first_run(const TailGeom& t, int64_t tt) {
-  return (int)(tt * t.stages / t.quota);
-}
-__host__ __device__ __forceinline__ int tail_pieces(const TailGeom& t, int64_t tt) {
-  return (int)(((tt + 1) * t.stages - 1) / t.quota) - tail_first_run(t, tt) + 1;
-}
-
 // AssignPlan::tail_order as a kernel argument
 struct TailOrder {
   int on;
@@ -699,7 +726,7 @@ template <int XT, int NW, int SK, bool GATED, bool MODE2>
 __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     const float* __restrict__ X, int64_t N, const float* __restrict__ C, int K,
     const float* __restrict__ aux, int stages_total, int tail_span, int full_tiles,
-    int64_t tail_units, int tail_quota, const float* __restrict__ thr, PartBufs pb,
+    int64_t tail_units, int tail_quota, int tail_long, const float* __restrict__ thr, PartBufs pb,
     float* __restrict__ rowband, uint32_t* __restrict__ zero_word,
     const int32_t* __restrict__ perm, TailOrder order) {
   static_assert(XT == 1, "one 32-descriptor tile per wave");
@@ -730,14 +757,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_top2_partial(
     // which run of the tail this workgroup walks (see AssignPlan::tail_order)
     const int b = (int)blockIdx.x - full_tiles;
     const int run = order.on ? (int)order.run[b < kMaxTailOrder ? b : 0] : b;
-    const int64_t u = (int64_t)run * tail_quota;
+    // (the first tail_long runs have tail_quota units, the others one less)
+    const TailGeom geom{tail_span, tail_quota, NW * 32, tail_long};
+    const int64_t u = tail_run_start(geom, run);
+    const int mine = run < tail_long ? tail_quota : tail_quota - 1;
     const int64_t tt = u / tail_span;
     const int64_t rest = tail_units - u;
     tile = full_tiles + (int)tt;
     st = (int)(u - tt * tail_span);
-    left = rest < tail_quota ? (int)rest : tail_quota;
+    left = rest < mine ? (int)rest : mine;
     if (tail_span != stages_total && left > stages_total - st) left = stages_total - st;
-    piece = run - (int)(tt * tail_span / tail_quota);
+    piece = run - tail_first_run(geom, tt);
   }
   const int64_t split_row0 = (int64_t)full_tiles * (NW * 32);
   const int n_rows = (int)N;
@@ -1143,9 +1173,17 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   const int64_t grid = plan.full_tiles + plan.tail_wgs;
   // the kernel's geometry must be the plan's: it indexes rows and records by it
   if (stages != plan.stages || plan.rows_per_wg != NW * 32 || plan.tail_quota < 1 ||
-      plan.tail_span < stages || (plan.tail_span != stages && plan.tail_span % plan.tail_quota != 0) ||
-      plan.tail_wgs != (tail_tiles * plan.tail_span + plan.tail_quota - 1) / plan.tail_quota)
+      plan.tail_span < stages || (plan.tail_span != stages && plan.tail_span % plan.tail_quota != 0))
     return hipErrorInvalidValue;
+  if (plan.tail_long >= plan.tail_wgs) {   // every run has tail_quota stages
+    if (plan.tail_wgs != (tail_tiles * plan.tail_span + plan.tail_quota - 1) / plan.tail_quota)
+      return hipErrorInvalidValue;
+  } else if (plan.tail_long < 1 || plan.tail_quota < 3 || plan.tail_span != stages ||
+             plan.tail_long * plan.tail_quota +
+                     (plan.tail_wgs - plan.tail_long) * (plan.tail_quota - 1) !=
+                 tail_tiles * plan.tail_span) {
+    return hipErrorInvalidValue;
+  }
   if (grid <= 0 || grid > 0x7fffffffLL || plan.full_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
   TailOrder order = {};
   order.on = plan.tail_ordered;
@@ -1158,8 +1196,9 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, x, n, c, (int)k, aux,
                      (int)stages, plan.tail_span, (int)plan.full_tiles,
-                     tail_tiles * plan.tail_span, plan.tail_quota, thr, pb, rowband, zero_word, perm,
-                     order);
+                     tail_tiles * plan.tail_span, plan.tail_quota,
+                     (int)(plan.tail_long < 0x7fffffff ? plan.tail_long : 0x7fffffff), thr, pb,
+                     rowband, zero_word, perm, order);
   return hipGetLastError();
 }
 
@@ -1833,7 +1872,7 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
   auto kern = D > kD ? k_rescore<true> : k_rescore<false>;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb,
-                     rowband, TailGeom{plan.tail_span, plan.tail_quota, plan.rows_per_wg},
+                     rowband, TailGeom{plan.tail_span, plan.tail_quota, plan.rows_per_wg, plan.tail_long},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
                      FinalOut{i1, d1, i2, d2, ratio, mask, rec}, list, count, tickets);
   return hipGetLastError();

@@ -30,6 +30,14 @@ struct AssignPlan {
   int64_t row_tiles, full_tiles;
   int tail_quota, max_pieces;
   int64_t tail_wgs;
+  // The first tail_long runs of the tail have tail_quota stages, the others one less (at least
+  // tail_wgs: every run has tail_quota).  The line of a partly filled round rarely divides by
+  // the number of workgroup slots: 391 row tiles x 16 stages on 512 slots are 12.2 stages a
+  // slot, and runs of 13 would fill only 482 slots, each for 13 stages' time.  With 112 runs of
+  // 13 and 400 of 12 every slot is used, and the long runs go to workgroup ids whose partner on
+  // the same CU (the id 256 further on, when the tail is the whole grid) has a short one: a CU
+  // then multiplies 25 stages instead of 26.
+  int64_t tail_long;
   int wide_pieces;                 // rows of 512 columns and more: every row tile is cut into this
                                    // many pieces of tail_quota stages whose workgroups share an
                                    // XCD (0: the line walk above)

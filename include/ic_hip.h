@@ -119,12 +119,13 @@ int ic_debug_flagged(void* handle, uint32_t* count); /* `count` must stay valid 
 
 /* Test hook, no counterpart in the reference, host arithmetic only (no handle, no GPU): how a
  * search of n rows x k codewords x d columns would be cut into workgroups on a device with
- * `num_cus` compute units.  out [14] int64: waves per workgroup, codewords per stage, rows per
+ * `num_cus` compute units.  out [15] int64: waves per workgroup, codewords per stage, rows per
  * workgroup, stages, places a row tile of the tail takes in the line of (row tile, stage) units,
  * row tiles, row tiles scanned whole, stages per workgroup of the tail, most pieces a row tile
  * falls into, workgroups of the tail, pieces per row tile of the wide search (0: none), records
  * of the partial buffer, 1 when the codebook stays in LDS whole and every wave walks 32-row tiles
- * on its own (else 0), workgroups of that launch.  The CPU tests replay the kernels' index
+ * on its own (else 0), workgroups of that launch, workgroups of the tail whose run has the full
+ * number of stages (the others have one less).  The CPU tests replay the kernels' index
  * arithmetic against it. */
 int ic_debug_plan(int64_t n, int64_t k, int d, int num_cus, int64_t* out);
 /* The same plan's hand-out of the tail's runs: order[b] = the run that workgroup b of the tail

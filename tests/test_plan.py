@@ -14,11 +14,23 @@ from image_classification_amd import _lib
 
 FIELDS = ("waves", "stage_k", "rows_per_wg", "stages", "tail_span", "row_tiles", "full_tiles",
           "tail_quota", "max_pieces", "tail_wgs", "wide_pieces", "records", "resident",
-          "resident_wgs")
+          "resident_wgs", "tail_long")
+
+
+def run_start(p, g):
+    """First unit of run g: the first tail_long runs have tail_quota units, the others one less."""
+    return g * p["tail_quota"] - max(0, g - p["tail_long"])
+
+
+def run_of(p, u):
+    q, long_units = p["tail_quota"], p["tail_long"] * p["tail_quota"]
+    if u < long_units or q < 2:
+        return u // q
+    return p["tail_long"] + (u - long_units) // (q - 1)
 
 
 def plan(n, k, d=128, cus=256):
-    out = (ctypes.c_int64 * 14)()
+    out = (ctypes.c_int64 * 15)()
     rc = _lib.load().ic_debug_plan(n, k, d, cus, out)
     assert rc == 0, _lib.last_error()
     return dict(zip(FIELDS, (int(v) for v in out)))
@@ -59,15 +71,15 @@ def walk(p, n, order=None):
         assert sorted(order) == list(range(p["tail_wgs"])), "the hand-out is not a permutation"
     for b in range(p["tail_wgs"]):
         g = order[b] if order else b
-        u = g * q
+        u = run_start(p, g)
         tt = u // span
         rest = tail_units - u
         tile = full + tt
         st = u - tt * span
-        left = min(rest, q)
+        left = min(rest, q if g < p["tail_long"] else q - 1)
         if span != S:
             left = min(left, S - st)
-        piece = g - tt * span // q
+        piece = g - run_of(p, tt * span)
         while left > 0:
             item = min(S - st, left)
             assert item >= 1
@@ -99,9 +111,9 @@ def check(n, k, d=128, cus=256):
         else:
             # what k_rescore takes the number of lists of a tail row tile to be
             tt = tile - p["full_tiles"]
-            span, q = p["tail_span"], p["tail_quota"]
-            first = tt * span // q
-            assert len(got) == ((tt + 1) * span - 1) // q - first + 1
+            span = p["tail_span"]
+            first = run_of(p, tt * span)
+            assert len(got) == run_of(p, (tt + 1) * span - 1) - first + 1
     # record slots (part_slot): lists 0 and 1 for every row, the others only for the tail's rows
     assert p["records"] == 2 * n + (2 * p["max_pieces"] - 2) * (n - split_row0)
     if p["resident"]:
@@ -179,15 +191,41 @@ def test_tail_runs_are_dealt_to_the_xcds_by_first_stage():
     p = plan(n, k)
     order = tail_order(n, k)
     assert len(order) == p["tail_wgs"] == 256 and p["tail_span"] == p["stages"]
-    S, q = p["stages"], p["tail_quota"]
+    S = p["stages"]
     last = -1
     for xcd in range(8):
-        starts = [(order[b] * q) % S for b in range(len(order)) if (p["full_tiles"] + b) % 8 == xcd]
-        assert starts == sorted(starts) and starts[0] >= last
-        assert starts[-1] - starts[0] <= S // 4       # a window of the codebook, not all of it
-        last = starts[-1]
+        mine = [order[b] for b in range(len(order)) if (p["full_tiles"] + b) % 8 == xcd]
+        # inside an XCD's window the long runs come first, each kind by first stage
+        kinds = [g < p["tail_long"] for g in mine]
+        assert kinds == sorted(kinds, reverse=True)
+        for kind in (True, False):
+            starts = [run_start(p, g) % S for g in mine if (g < p["tail_long"]) == kind]
+            assert starts == sorted(starts)
+        starts = [run_start(p, g) % S for g in mine]
+        assert min(starts) >= last
+        assert max(starts) - min(starts) <= S // 4    # a window of the codebook, not all of it
+        last = max(starts)
     # aligned pieces and the wide search keep the plain order
     assert tail_order(4000, 2_000_000 // 64) == [] and tail_order(100_000, 600, 1937) == []
+
+
+def test_runs_of_two_lengths_fill_every_slot():
+    # BASELINE config 1: 391 row tiles x 16 stages = 6256 units on 512 slots: 112 runs of 13
+    # stages and 400 of 12 instead of 482 runs of 13, and no CU (workgroups b and b + 256) gets
+    # two long ones
+    n, k = 100_000, 1000
+    p = plan(n, k)
+    assert (p["tail_wgs"], p["tail_quota"], p["tail_long"], p["full_tiles"]) == (512, 13, 112, 0)
+    order = tail_order(n, k)
+    assert sorted(order) == list(range(512))
+    long_at = [order[b] < p["tail_long"] for b in range(512)]
+    assert sum(long_at) == 112
+    assert not any(long_at[b] and long_at[b + 256] for b in range(256))
+    lengths = [13 if g < 112 else 12 for g in range(512)]
+    assert sum(lengths) == 391 * 16 and run_start(p, 511) + 12 == 391 * 16
+    # a line that divides evenly keeps runs of one length
+    q = plan(256 * 256, 64 * 16)
+    assert q["tail_long"] == q["tail_wgs"]
 
 
 def test_small_codebooks_stay_in_lds_from_many_rows_on():
@@ -199,7 +237,7 @@ def test_small_codebooks_stay_in_lds_from_many_rows_on():
 
 
 def test_bad_arguments_are_refused():
-    out = (ctypes.c_int64 * 14)()
+    out = (ctypes.c_int64 * 15)()
     lib = _lib.load()
     assert lib.ic_debug_plan(0, 10, 128, 256, out) != 0
     assert lib.ic_debug_plan(10, 0, 128, 256, out) != 0
