@@ -154,7 +154,13 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
     return v ? atoi(v) : 0;
   }();
   // rows wider than 128 columns always take the 8-wave geometry (k_top2_wide has no other)
-  const bool small = wide || geom == 1 || (geom != 2 && k < kSmallCodebook);
+  // ... and so do few rows against a long codebook: when the 16-wave geometry has fewer than two
+  // (row tile, stage) units per CU, most CUs would stay idle while the others multiply runs of
+  // two 128-word stages (one image's 1000 descriptors against 10 000 words: 79 workgroups,
+  // 77 us; the 8-wave geometry's 256-row tiles and 64-word stages give 314)
+  const bool few = geom == 0 && !wide && k >= kSmallCodebook &&
+                   ((n + 511) / 512) * ((k + 127) / 128) < 2 * (int64_t)num_cus;
+  const bool small = wide || few || geom == 1 || (geom != 2 && k < kSmallCodebook);
   p->waves = small ? 8 : 16;
   p->stage_k = small ? 64 : 128;
   p->rows_per_wg = kXT * p->waves * 32;
@@ -1671,6 +1677,8 @@ __device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, floa
 // WIDE: rows of D = 128 nslab columns (row stride D).  A row no longer fits a group's registers,
 // so every direct evaluation walks the row's slabs again (they stay in cache between the
 // candidates of a row), adding slab after slab in the order k_exact_top2 uses.
+constexpr int kListBatch = 8;   // lists of a row whose records are fetched together
+
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
@@ -1716,13 +1724,74 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     hd.v3 = pb.d3[row];
     hd.u3 = unnamed[row];
     const int ns = n_lists(row);
-    for (int s = 1; s < ns; ++s) {
-      const int64_t slot = part_slot(s, row, N, split_row0);
-      const ic_top2_rec o = pb.rec[slot];
-      const float o3 = pb.d3[slot];
-      hd.u3 = __builtin_fminf(hd.u3, unnamed[slot]);
+    auto take = [&](const ic_top2_rec& o, float o3, float ou) {
+      hd.u3 = __builtin_fminf(hd.u3, ou);
       hd.v3 = third_of_union(hd.b.d1, hd.b.d2, hd.v3, o.d1, o.d2, o3);
       top2_merge_pairs(hd.b.d1, hd.b.i1, hd.b.d2, hd.b.i2, o.d1, o.i1, o.d2, o.i2);
+    };
+    // (few rows against a long codebook are cut into dozens of pieces: eight lists' loads go
+    // out together, so that a row's merge is a few round trips to memory and not one per list)
+    int s = 1;
+    for (; s + kListBatch <= ns; s += kListBatch) {
+      ic_top2_rec o[kListBatch];
+      float o3[kListBatch], ou[kListBatch];
+#pragma unroll
+      for (int u = 0; u < kListBatch; ++u) {
+        const int64_t slot = part_slot(s + u, row, N, split_row0);
+        o[u] = pb.rec[slot];
+        o3[u] = pb.d3[slot];
+        ou[u] = unnamed[slot];
+      }
+#pragma unroll
+      for (int u = 0; u < kListBatch; ++u) take(o[u], o3[u], ou[u]);
+    }
+    for (; s < ns; ++s) {
+      const int64_t slot = part_slot(s, row, N, split_row0);
+      take(pb.rec[slot], pb.d3[slot], unnamed[slot]);
+    }
+    return hd;
+  };
+
+  // The same merge by the 16 lanes of a group, for rows cut into many pieces (few rows against a
+  // long codebook: 79 pieces and more per row tile): lane `sub` takes the lists sub, sub + 16, ...,
+  // eight loads in flight, and the sixteen partial heads are folded by a butterfly -- two or
+  // three round trips to memory per row instead of one per list.  Every lane returns the row's
+  // head.  (Which of several lists' "none" entries survives depends on the order of merging;
+  // their values are the row's start value in every list.)
+  auto merge_lists_group = [&](int64_t row) {
+    Head hd;
+    hd.b.d1 = hd.b.d2 = hd.v3 = hd.u3 = __builtin_inff();
+    hd.b.i1 = hd.b.i2 = -1;
+    const int ns = n_lists(row);
+    auto take = [&](const ic_top2_rec& o, float o3, float ou) {
+      hd.u3 = __builtin_fminf(hd.u3, ou);
+      hd.v3 = third_of_union(hd.b.d1, hd.b.d2, hd.v3, o.d1, o.d2, o3);
+      top2_merge_pairs(hd.b.d1, hd.b.i1, hd.b.d2, hd.b.i2, o.d1, o.i1, o.d2, o.i2);
+    };
+    for (int s0 = 0; s0 < ns; s0 += 16 * kListBatch) {   // uniform in the group
+      ic_top2_rec o[kListBatch];
+      float o3[kListBatch], ou[kListBatch];
+#pragma unroll
+      for (int u = 0; u < kListBatch; ++u) {
+        const int l = s0 + 16 * u + sub;
+        const int64_t slot = part_slot(l < ns ? l : 0, row, N, split_row0);
+        o[u] = pb.rec[slot];
+        o3[u] = pb.d3[slot];
+        ou[u] = unnamed[slot];
+      }
+#pragma unroll
+      for (int u = 0; u < kListBatch; ++u)
+        if (s0 + 16 * u + sub < ns) take(o[u], o3[u], ou[u]);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      ic_top2_rec o;
+      o.d1 = __shfl_xor(hd.b.d1, off);
+      o.i1 = __shfl_xor(hd.b.i1, off);
+      o.d2 = __shfl_xor(hd.b.d2, off);
+      o.i2 = __shfl_xor(hd.b.i2, off);
+      const float o3 = __shfl_xor(hd.v3, off), ou = __shfl_xor(hd.u3, off);
+      take(o, o3, ou);
     }
     return hd;
   };
@@ -1807,7 +1876,23 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     }
   };
 
-  if (rowband == nullptr) {
+  // (uniform in the workgroup: its rows belong to one row tile or to neighbouring ones)
+  const bool many = row_begin < row_end &&
+                    (n_lists(row_begin) > 2 * kListBatch || n_lists(row_end - 1) > 2 * kListBatch);
+  if (many) {
+    for (int64_t row = row_begin + grp; row < row_end; row += 16) {
+      const Head hd = merge_lists_group(row);
+      if (rowband) {
+        // the shortcut of the index-only search, see below
+        const float band = __builtin_fmaf(hd.b.d1, band_slope, rowband[row]);
+        if (hd.b.i1 >= 0 && (hd.b.d2 - hd.b.d1) > band) {   // the same in all 16 lanes
+          if (sub == 0) out.i1[row] = hd.b.i1;
+          continue;
+        }
+      }
+      full_look(row, hd);
+    }
+  } else if (rowband == nullptr) {
     // the lists of 256 rows are merged by one thread each (coalesced record reads, one round
     // trip for all of them), then the groups evaluate the rows: a row's chain of dependent loads
     // is one step (row + codewords) instead of two (record, then codewords)
@@ -1827,7 +1912,16 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       if (row < row_end) {
         ic_top2_rec b = pb.rec[row];
         const int ns = n_lists(row);
-        for (int s = 1; s < ns; ++s) {
+        int s = 1;
+        for (; s + kListBatch <= ns; s += kListBatch) {
+          ic_top2_rec o[kListBatch];
+#pragma unroll
+          for (int u = 0; u < kListBatch; ++u) o[u] = pb.rec[part_slot(s + u, row, N, split_row0)];
+#pragma unroll
+          for (int u = 0; u < kListBatch; ++u)
+            top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o[u].d1, o[u].i1, o[u].d2, o[u].i2);
+        }
+        for (; s < ns; ++s) {
           const ic_top2_rec o = pb.rec[part_slot(s, row, N, split_row0)];
           top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
         }
@@ -1864,6 +1958,12 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   // the shortcut path looks at one row per thread: whole blocks of 256 rows per workgroup
   int64_t chunk = rescore_chunk(n);
   if (rowband && chunk < 256) chunk = 256;
+  // every row cut into many pieces (few rows, long codebook): the kernel merges a row's lists by
+  // a group of 16 lanes, so a workgroup takes 16 rows and they all go on at once
+  if (plan.full_tiles == 0 && plan.max_pieces > kListBatch) {
+    chunk = (n + 16383) / 16384;
+    chunk = (chunk + 15) / 16 * 16;
+  }
   const int64_t grid = (n + chunk - 1) / chunk;
   if (grid < 1 || n >= 0x7fffffffLL) return hipErrorInvalidValue;
   // the shortcut answers with an index only
