@@ -82,6 +82,11 @@ class HipBackend(object):
         list of host arrays: small inputs in three plain steps, large ones through the pipeline
         that takes histogram blocks down while later rows are still being searched."""
         total = sum(p.shape[0] for p in parts)
+        if 0 < total <= ops.HOST_CHUNK_ROWS // 4:
+            # the images' offsets ride behind the rows in one upload
+            x, off = ops.upload_parts(parts, self.device, extra_i64=offsets)
+            codes, _ = self.assign_top1(x, cb, want_dist=False)
+            return codes, self.to_host(self.hist(codes, off, k, norm, power))
         if total <= ops.HOST_CHUNK_ROWS * 2:
             # (the offsets go up first: a copy from pageable memory blocks the caller until
             # everything enqueued before it has run, which would otherwise include the search)

@@ -300,12 +300,16 @@ _small_stage = {}                 # pid -> [page-locked buffer, event of its las
 SMALL_STAGE_BYTES = 16 << 20
 
 
-def upload_parts(parts, device):
+def upload_parts(parts, device, extra_i64=None):
     """float32 device tensor [sum n_i, d] of a short list of host arrays (the candidates of one
     RobustMatcher.match call, the images of one small extract call): the rows are laid into a
     page-locked buffer by the native gather and leave it in one asynchronous copy on the current
     stream.  np.concatenate followed by a copy from pageable memory costs the caller about twice
-    the link time of the rows (0.17 ms for 5 MB), during which it cannot enqueue anything."""
+    the link time of the rows (0.17 ms for 5 MB), during which it cannot enqueue anything.
+
+    extra_i64 (the images' row offsets): a short int64 array that rides behind the rows in the
+    same copy -- a separate upload of a few bytes from pageable memory costs a per-image call
+    20 to 30 us; the result is then (rows, int64 device tensor)."""
     d = parts[0].shape[1]
     n = 0
     own = False
@@ -317,9 +321,15 @@ def upload_parts(parts, device):
             if not own:
                 parts, own = list(parts), True
             parts[i] = np.ascontiguousarray(p, dtype=np.float32)
-    if n * d * 4 > SMALL_STAGE_BYTES or n == 0:
+    if extra_i64 is not None:
+        extra_i64 = np.ascontiguousarray(extra_i64, dtype=np.int64).reshape(-1)
+    n_extra = 0 if extra_i64 is None else 2 * extra_i64.size      # in float32 slots
+    if (n * d + 1 + n_extra) * 4 > SMALL_STAGE_BYTES or n == 0:
         x_np = parts[0] if len(parts) == 1 else np.concatenate(parts)
-        return as_device_f32(x_np, device)
+        xd = as_device_f32(x_np, device)
+        if extra_i64 is None:
+            return xd
+        return xd, torch.from_numpy(extra_i64).to(device)
     with _staging_lock:
         st = _small_stage.get(os.getpid())
         if st is None:
@@ -330,11 +340,17 @@ def upload_parts(parts, device):
         if st[1] is not None:
             st[1].synchronize()           # the previous upload has left the buffer
         _gather_rows(st[0], [(p, 0, p.shape[0]) for p in parts if p.shape[0]], d, threads=2)
-        xd = torch.empty((n, d), dtype=torch.float32, device=device)
-        xd.copy_(st[0][:n * d].view(n, d), non_blocking=True)
+        at = (n * d + 1) // 2 * 2                  # the int64 payload starts on 8 bytes
+        if n_extra:
+            st[0][at:at + n_extra].view(torch.int64).numpy()[:] = extra_i64
+        buf = torch.empty(at + n_extra, dtype=torch.float32, device=device)
+        buf.copy_(st[0][:at + n_extra], non_blocking=True)
         st[1] = torch.cuda.Event()
         st[1].record(torch.cuda.current_stream(device))
-    return xd
+    xd = buf[:n * d].view(n, d)
+    if extra_i64 is None:
+        return xd
+    return xd, buf[at:at + n_extra].view(torch.int64)
 
 
 def assign_from_host_parts(parts, c, c_aux=None, top2=False, ratio=0.8, want_dist=True,
