@@ -1731,23 +1731,20 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     };
     // (few rows against a long codebook are cut into dozens of pieces: eight lists' loads go
     // out together, so that a row's merge is a few round trips to memory and not one per list)
-    int s = 1;
-    for (; s + kListBatch <= ns; s += kListBatch) {
+    // (a short last batch reads list 0 again in the places it does not have and drops them)
+    for (int s = 1; s < ns; s += kListBatch) {
       ic_top2_rec o[kListBatch];
       float o3[kListBatch], ou[kListBatch];
 #pragma unroll
       for (int u = 0; u < kListBatch; ++u) {
-        const int64_t slot = part_slot(s + u, row, N, split_row0);
+        const int64_t slot = part_slot(s + u < ns ? s + u : 0, row, N, split_row0);
         o[u] = pb.rec[slot];
         o3[u] = pb.d3[slot];
         ou[u] = unnamed[slot];
       }
 #pragma unroll
-      for (int u = 0; u < kListBatch; ++u) take(o[u], o3[u], ou[u]);
-    }
-    for (; s < ns; ++s) {
-      const int64_t slot = part_slot(s, row, N, split_row0);
-      take(pb.rec[slot], pb.d3[slot], unnamed[slot]);
+      for (int u = 0; u < kListBatch; ++u)
+        if (s + u < ns) take(o[u], o3[u], ou[u]);
     }
     return hd;
   };
@@ -1912,18 +1909,15 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       if (row < row_end) {
         ic_top2_rec b = pb.rec[row];
         const int ns = n_lists(row);
-        int s = 1;
-        for (; s + kListBatch <= ns; s += kListBatch) {
+        for (int s = 1; s < ns; s += kListBatch) {
           ic_top2_rec o[kListBatch];
 #pragma unroll
-          for (int u = 0; u < kListBatch; ++u) o[u] = pb.rec[part_slot(s + u, row, N, split_row0)];
+          for (int u = 0; u < kListBatch; ++u)
+            o[u] = pb.rec[part_slot(s + u < ns ? s + u : 0, row, N, split_row0)];
 #pragma unroll
           for (int u = 0; u < kListBatch; ++u)
-            top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o[u].d1, o[u].i1, o[u].d2, o[u].i2);
-        }
-        for (; s < ns; ++s) {
-          const ic_top2_rec o = pb.rec[part_slot(s, row, N, split_row0)];
-          top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
+            if (s + u < ns)
+              top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o[u].d1, o[u].i1, o[u].d2, o[u].i2);
         }
         // the gate's band of the best: everything outside the pair lies above b.d2 or was
         // never ranked, and what was never ranked lies above this band as well
@@ -1942,12 +1936,13 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
   }
 }
 
-// Rows per workgroup of k_rescore: few, so that many independent gathers are in flight, but never
-// more than 16384 workgroups.
+// Rows per workgroup of k_rescore: few, so that many independent gathers are in flight -- one row
+// per 16-lane group while that gives no more than 16384 workgroups (a call with a few thousand
+// rows is one round trip to memory per step, not four).
 int64_t rescore_chunk(int64_t n) {
   int64_t chunk = (n + 16383) / 16384;
   chunk = (chunk + 15) / 16 * 16;
-  return chunk < 64 ? 64 : chunk;
+  return chunk < 16 ? 16 : chunk;
 }
 
 hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float* aux,
