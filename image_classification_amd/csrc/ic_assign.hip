@@ -263,7 +263,7 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   }
   // Runs of two lengths (see AssignPlan::tail_long): q stages for the first n_long runs, q - 1
   // for the others, one run per slot.
-  if (forced <= 0 && !wide && p->tail_span == (int)stages && q >= 3 && units > (q - 1) * slots &&
+  if (forced <= 0 && !wide && p->tail_span == (int)stages && q >= 2 && units > (q - 1) * slots &&
       units < q * slots) {
     p->tail_long = units - (q - 1) * slots;
     p->tail_wgs = slots;
@@ -1184,7 +1184,7 @@ static hipError_t launch_geometry(const float* x, int64_t n, const float* c, int
   if (plan.tail_long >= plan.tail_wgs) {   // every run has tail_quota stages
     if (plan.tail_wgs != (tail_tiles * plan.tail_span + plan.tail_quota - 1) / plan.tail_quota)
       return hipErrorInvalidValue;
-  } else if (plan.tail_long < 1 || plan.tail_quota < 3 || plan.tail_span != stages ||
+  } else if (plan.tail_long < 1 || plan.tail_quota < 2 || plan.tail_span != stages ||
              plan.tail_long * plan.tail_quota +
                      (plan.tail_wgs - plan.tail_long) * (plan.tail_quota - 1) !=
                  tail_tiles * plan.tail_span) {
