@@ -76,6 +76,25 @@ def test_hist_images_whose_codes_fall_on_a_few_words(words):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("n_img,k", [(1, 10000), (3, 1025), (63, 4001), (2, 40000), (1, 70001)])
+def test_hist_few_long_rows_are_cut_into_bin_ranges(n_img, k):
+    # one image per call, as the reference's flow issues them: raw and L1 rows are counted by
+    # several workgroups, one bin range each (an L1 row's sum is its number of codes, which every
+    # range knows); codes outside the vocabulary count nowhere, not even in the sum
+    rng = np.random.default_rng(n_img * k)
+    offsets = image_offsets(n_img, 1500, ragged=n_img > 2, seed=k)
+    codes = rng.integers(0, k, size=offsets[-1]).astype(np.int32)
+    codes[::97] = -1
+    codes[5::101] = k + 3
+    for norm in ("none", "l1", "l2"):
+        got = _hist(codes, offsets, k, norm)
+        ref = oracle.build_histogram(_split(codes, offsets), k, norm)
+        if norm == "l2":
+            assert oracle.check_close(got, ref, rel=1e-12, abs_floor=1e-300) <= 1e-12
+        else:
+            assert np.array_equal(got, ref)
+
+
 def test_hist_ignores_codes_outside_the_vocabulary():
     codes = np.array([0, 5, -1, 7, 99, 5, 2 ** 31 - 1], dtype=np.int32)
     got = _hist(codes, [0, 7], 8, "l1")
