@@ -1679,7 +1679,9 @@ __device__ __forceinline__ void write_final(const FinalOut& o, int64_t row, floa
 // candidates of a row), adding slab after slab in the order k_exact_top2 uses.
 constexpr int kListBatch = 8;   // lists of a row whose records are fetched together
 
-template <bool WIDE>
+// MANY: every row is cut into many pieces and a group of 16 lanes merges a row's lists (its own
+// instantiation: the common one keeps the registers, and the occupancy, it had without that code)
+template <bool WIDE, bool MANY>
 __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, int64_t N,
                                                  const float* __restrict__ C,
                                                  const float* __restrict__ aux, int D,
@@ -1729,22 +1731,9 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       hd.v3 = third_of_union(hd.b.d1, hd.b.d2, hd.v3, o.d1, o.d2, o3);
       top2_merge_pairs(hd.b.d1, hd.b.i1, hd.b.d2, hd.b.i2, o.d1, o.i1, o.d2, o.i2);
     };
-    // (few rows against a long codebook are cut into dozens of pieces: eight lists' loads go
-    // out together, so that a row's merge is a few round trips to memory and not one per list)
-    // (a short last batch reads list 0 again in the places it does not have and drops them)
-    for (int s = 1; s < ns; s += kListBatch) {
-      ic_top2_rec o[kListBatch];
-      float o3[kListBatch], ou[kListBatch];
-#pragma unroll
-      for (int u = 0; u < kListBatch; ++u) {
-        const int64_t slot = part_slot(s + u < ns ? s + u : 0, row, N, split_row0);
-        o[u] = pb.rec[slot];
-        o3[u] = pb.d3[slot];
-        ou[u] = unnamed[slot];
-      }
-#pragma unroll
-      for (int u = 0; u < kListBatch; ++u)
-        if (s + u < ns) take(o[u], o3[u], ou[u]);
+    for (int s = 1; s < ns; ++s) {
+      const int64_t slot = part_slot(s, row, N, split_row0);
+      take(pb.rec[slot], pb.d3[slot], unnamed[slot]);
     }
     return hd;
   };
@@ -1873,10 +1862,7 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
     }
   };
 
-  // (uniform in the workgroup: its rows belong to one row tile or to neighbouring ones)
-  const bool many = row_begin < row_end &&
-                    (n_lists(row_begin) > 2 * kListBatch || n_lists(row_end - 1) > 2 * kListBatch);
-  if (many) {
+  if constexpr (MANY) {
     for (int64_t row = row_begin + grp; row < row_end; row += 16) {
       const Head hd = merge_lists_group(row);
       if (rowband) {
@@ -1909,15 +1895,9 @@ __global__ __launch_bounds__(256) void k_rescore(const float* __restrict__ X, in
       if (row < row_end) {
         ic_top2_rec b = pb.rec[row];
         const int ns = n_lists(row);
-        for (int s = 1; s < ns; s += kListBatch) {
-          ic_top2_rec o[kListBatch];
-#pragma unroll
-          for (int u = 0; u < kListBatch; ++u)
-            o[u] = pb.rec[part_slot(s + u < ns ? s + u : 0, row, N, split_row0)];
-#pragma unroll
-          for (int u = 0; u < kListBatch; ++u)
-            if (s + u < ns)
-              top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o[u].d1, o[u].i1, o[u].d2, o[u].i2);
+        for (int s = 1; s < ns; ++s) {
+          const ic_top2_rec o = pb.rec[part_slot(s, row, N, split_row0)];
+          top2_merge_pairs(b.d1, b.i1, b.d2, b.i2, o.d1, o.i1, o.d2, o.i2);
         }
         // the gate's band of the best: everything outside the pair lies above b.d2 or was
         // never ranked, and what was never ranked lies above this band as well
@@ -1955,7 +1935,8 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (rowband && chunk < 256) chunk = 256;
   // every row cut into many pieces (few rows, long codebook): the kernel merges a row's lists by
   // a group of 16 lanes, so a workgroup takes 16 rows and they all go on at once
-  if (plan.full_tiles == 0 && plan.max_pieces > kListBatch) {
+  const bool many = plan.full_tiles == 0 && plan.max_pieces > kListBatch;
+  if (many) {
     chunk = (n + 16383) / 16384;
     chunk = (chunk + 15) / 16 * 16;
   }
@@ -1965,7 +1946,8 @@ hipError_t launch_rescore(const float* x, int64_t n, const float* c, const float
   if (rowband && (mode2 || d1 || !i1)) return hipErrorInvalidValue;
   if (mode2 && (!pb.i3 || !pb.d4)) return hipErrorInvalidValue;
   if (D < kD || D % kD != 0 || D > kMaxWideD) return hipErrorInvalidValue;
-  auto kern = D > kD ? k_rescore<true> : k_rescore<false>;
+  auto kern = many ? (D > kD ? k_rescore<true, true> : k_rescore<false, true>)
+                   : (D > kD ? k_rescore<true, false> : k_rescore<false, false>);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, x, n, c, aux, D, mean, pb,
                      rowband, TailGeom{plan.tail_span, plan.tail_quota, plan.rows_per_wg, plan.tail_long},
                      plan.full_tiles * (int64_t)plan.rows_per_wg, mode2 ? 1 : 0, chunk,
