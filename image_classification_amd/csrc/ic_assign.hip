@@ -236,7 +236,9 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
   if (forced <= 0 && (slots - tail) * stages <= 2 * (int64_t)slots) return;
   const int64_t units = tail * stages;
   int64_t q = forced > 0 ? forced : (units + slots - 1) / slots;
-  const int64_t q_min = stages < 2 ? stages : 2;   // one-stage runs only reload row tiles
+  // one-stage runs only reload row tiles -- unless the whole search is less than one stage a
+  // slot: then nothing is gained by leaving slots empty, and a call's latency is what counts
+  const int64_t q_min = (stages < 2 || units <= slots) ? 1 : 2;
   if (q < q_min) q = q_min;
   if (q > stages) q = stages;                      // (only when forced)
   p->tail_quota = (int)q;
@@ -254,7 +256,7 @@ void assign_plan(int64_t n, int64_t k, int num_cus, AssignPlan* p, int D) {
     const int64_t P = slots / tail / 8 * 8;
     const int64_t qa = (stages + P - 1) / P;
     const int64_t Pa = (stages + qa - 1) / qa;     // pieces that are not empty
-    if (qa >= 2 && Pa * qa * 100 <= stages * 102 && qa * 100 <= q * 102) {
+    if (qa >= q_min && Pa * qa * 100 <= stages * 102 && qa * 100 <= q * 102) {
       p->tail_quota = (int)qa;
       p->tail_span = (int)(Pa * qa);
       p->tail_wgs = tail * Pa;
